@@ -1,0 +1,661 @@
+"""CPU oracle for the IEA-GAN G+D train step  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A plain-PyTorch (CPU, fp32) *functional* restatement of the reference hot path.  Networks are
+evaluated directly from a flat ``state_dict``-style mapping (same key names / shapes as the
+reference modules), every random draw is an explicit argument, and every in-place buffer update of
+the reference (spectral-norm ``u0``/``sv0``, BN running statistics) is an explicit write into that
+mapping.  Nothing in here is imported by the product package (``iea-gan_amd/``): only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may use it, and only as
+the checker.
+
+Pinning: ``tests/golden/make_golden.py`` (run in the development container, where
+``/root/reference`` is importable) drives the *reference* modules and this file with identical
+weights / noise and asserts agreement before it writes the fixtures under ``tests/golden/``;
+``tests/test_oracle_golden.py`` re-checks this file against those fixtures without the reference.
+
+Every function cites the reference lines it restates (paths relative to the reference root).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+State = Dict[str, Tensor]
+
+# --------------------------------------------------------------------------------------------
+# architecture tables                                     (model.py:74-136 G_arch, 561-621 D_arch)
+# --------------------------------------------------------------------------------------------
+_G_MULT = {  # resolution -> (in multipliers, out multipliers); every stage upsamples
+    512: ([16, 16, 8, 8, 4, 2, 1], [16, 8, 8, 4, 2, 1, 1]),
+    256: ([16, 16, 8, 8, 4, 2], [16, 8, 8, 4, 2, 1]),
+    128: ([16, 16, 8, 4, 2], [16, 8, 4, 2, 1]),
+    64: ([16, 16, 8, 4], [16, 8, 4, 2]),
+}
+_D_MULT = {  # resolution -> (in multipliers, out multipliers, nominal feature-map resolutions)
+    512: ([1, 1, 2, 4, 8, 8, 16], [1, 2, 4, 8, 8, 16, 16], [256, 128, 64, 32, 16, 8, 4, 4]),
+    256: ([1, 2, 4, 8, 8, 16], [2, 4, 8, 8, 16, 16], [128, 64, 32, 16, 8, 4, 4]),
+    128: ([1, 2, 4, 8, 16], [2, 4, 8, 16, 16], [64, 32, 16, 8, 4, 4]),
+    64: ([1, 2, 4, 8], [2, 4, 8, 16], [32, 16, 8, 4, 4]),
+}
+
+
+def g_stages(cfg) -> list:
+    """[(block_index, in_ch, out_ch, upsample)] for the flattened GBlock list (model.py:326-346)."""
+    ins, outs = _G_MULT[cfg["resolution"]]
+    ch, depth = cfg["G_ch"], cfg.get("G_depth", 2)
+    out = []
+    for s, (ci, co) in enumerate(zip(ins, outs)):
+        for g in range(depth):
+            out.append((s, g, ch * ci, ch * ci if g == 0 else ch * co, g == depth - 1))
+    return out
+
+
+def d_stages(cfg) -> list:
+    """[(stage, d_index, in_ch, out_ch, downsample, preact, attention_after)] (model.py:734-776)."""
+    ins, outs, res = _D_MULT[cfg["resolution"]]
+    ch, depth = cfg["D_ch"], cfg.get("D_depth", 2)
+    attn = [int(a) for a in str(cfg.get("D_attn", "0")).split("_")]
+    out = []
+    for s, (ci, co) in enumerate(zip(ins, outs)):
+        for d in range(depth):
+            out.append((s, d, ch * ci if d == 0 else ch * co, ch * co, d == 0,
+                        (s > 0 or d > 0), (d == depth - 1) and (res[s] in attn)))
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# spectral norm                                                        (layers.py:89-111, 151-165)
+# --------------------------------------------------------------------------------------------
+def sn_weight(sd: State, prefix: str, training: bool, eps: float) -> Tensor:
+    """One power iteration, one singular value.  Returns weight / sigma; sigma carries gradient
+    w.r.t. the weight with (u, v) held constant; ``u0`` is overwritten iff training and ``sv0``
+    records sigma iff training (layers.py:94-111, 156-165)."""
+    W = sd[prefix + ".weight"]
+    Wm = W.reshape(W.shape[0], -1)
+    u = sd[prefix + ".u0"]
+    with torch.no_grad():
+        v = F.normalize(u @ Wm, eps=eps)
+        u_new = F.normalize(v @ Wm.t(), eps=eps)
+        if training:
+            u.copy_(u_new)
+    sigma = ((v @ Wm.t()) @ u_new.t()).squeeze()
+    if training:
+        with torch.no_grad():
+            sd[prefix + ".sv0"][:] = sigma
+    return W / sigma
+
+
+def _has_sn(sd: State, prefix: str) -> bool:
+    return (prefix + ".u0") in sd
+
+
+def _weight(sd, prefix, training, eps):
+    return sn_weight(sd, prefix, training, eps) if _has_sn(sd, prefix) else sd[prefix + ".weight"]
+
+
+def conv(sd, prefix, x, training, eps, padding):
+    """SNConv2d.forward (layers.py:197-206)."""
+    return F.conv2d(x, _weight(sd, prefix, training, eps), sd.get(prefix + ".bias"), 1, padding)
+
+
+def linear(sd, prefix, x, training, eps):
+    """SNLinear.forward (layers.py:223-224) / nn.Linear."""
+    return F.linear(x, _weight(sd, prefix, training, eps), sd.get(prefix + ".bias"))
+
+
+def embedding(sd, prefix, idx, training, eps):
+    """SNEmbedding.forward (layers.py:258-259) / nn.Embedding."""
+    return F.embedding(idx, _weight(sd, prefix, training, eps))
+
+
+# --------------------------------------------------------------------------------------------
+# normalisation                                                      (layers.py:656-689, 728-742)
+# --------------------------------------------------------------------------------------------
+def ccbn(sd, prefix, x, y, training, bn_eps, sn_eps):
+    """Class-conditional BN: batch_norm without affine, then out*(1+gain(y)) + bias(y)."""
+    gain = (1 + linear(sd, prefix + ".gain", y, training, sn_eps)).view(y.size(0), -1, 1, 1)
+    bias = linear(sd, prefix + ".bias", y, training, sn_eps).view(y.size(0), -1, 1, 1)
+    out = F.batch_norm(x, sd[prefix + ".stored_mean"], sd[prefix + ".stored_var"], None, None,
+                       training, 0.1, bn_eps)
+    return out * gain + bias
+
+
+def plain_bn(sd, prefix, x, training, bn_eps):
+    """layers.bn.forward (layers.py:728-742): per-channel affine, momentum 0.1."""
+    return F.batch_norm(x, sd[prefix + ".stored_mean"], sd[prefix + ".stored_var"],
+                        sd[prefix + ".gain"], sd[prefix + ".bias"], training, 0.1, bn_eps)
+
+
+# --------------------------------------------------------------------------------------------
+# relational reasoning module                                                  (RRM.py:10-133)
+# --------------------------------------------------------------------------------------------
+def rrm(sd, prefix, x, num_heads, training, sn_eps):
+    """Pre-LN encoder (one or more layers) + final LayerNorm over [B, S, E] tokens.
+    qkv is packed head-interleaved: reshape(B,S,H,3*hd) then chunk (RRM.py:49-53)."""
+    li = 0
+    while f"{prefix}.layers.{li}.norm1.weight" in sd:
+        p = f"{prefix}.layers.{li}"
+        B, S, E = x.shape
+        hd = E // num_heads
+        x1 = F.layer_norm(x, (E,), sd[p + ".norm1.weight"], sd[p + ".norm1.bias"], 1e-5)
+        qkv = linear(sd, p + ".self_attn.qkv_proj", x1, training, sn_eps)
+        qkv = qkv.reshape(B, S, num_heads, 3 * hd).permute(0, 2, 1, 3)
+        q, k, v = qkv.chunk(3, dim=-1)
+        att = F.softmax(q @ k.transpose(-2, -1) / math.sqrt(hd), dim=-1)        # RRM.py:10-16
+        vals = (att @ v).permute(0, 2, 1, 3).reshape(B, S, E)
+        x = x + linear(sd, p + ".self_attn.o_proj", vals, training, sn_eps)      # RRM.py:98-102
+        x2 = F.layer_norm(x, (E,), sd[p + ".norm2.weight"], sd[p + ".norm2.bias"], 1e-5)
+        ff = linear(sd, p + ".linear_net.0", x2, training, sn_eps)
+        ff = linear(sd, p + ".linear_net.3", F.relu(ff), training, sn_eps)
+        x = x + ff                                                               # RRM.py:104-107
+        li += 1
+    E = x.shape[-1]
+    return F.layer_norm(x, (E,), sd[prefix + ".norm.weight"], sd[prefix + ".norm.bias"], 1e-5)
+
+
+# --------------------------------------------------------------------------------------------
+# generator                                                                  (model.py:54-71, 454-487)
+# --------------------------------------------------------------------------------------------
+def g_block(sd, p, x, y, cin, cout, upsample, training, cfg):
+    be, se = cfg["BN_eps"], cfg["SN_eps"]
+    h = conv(sd, p + ".conv1", F.relu(ccbn(sd, p + ".bn1", x, y, training, be, se)), training, se, 0)
+    h = F.relu(ccbn(sd, p + ".bn2", h, y, training, be, se))
+    if cin != cout:
+        x = x[:, :cout]
+    if upsample:
+        h = F.interpolate(h, scale_factor=2)
+        x = F.interpolate(x, scale_factor=2)
+    h = conv(sd, p + ".conv2", h, training, se, 1)
+    h = conv(sd, p + ".conv3", F.relu(ccbn(sd, p + ".bn3", h, y, training, be, se)), training, se, 1)
+    h = conv(sd, p + ".conv4", F.relu(ccbn(sd, p + ".bn4", h, y, training, be, se)), training, se, 0)
+    return h + x
+
+
+def generator(sd: State, cfg, z: Tensor, y: Tensor, rdof: Tensor, training: bool = True) -> Tensor:
+    """model.Generator.forward (model.py:454-487) for G_shared / hier / RRM_prx_G / no prior_embed.
+    ``rdof`` is the explicit stand-in for ``torch.randn(40, rdof_dim)`` at model.py:466."""
+    se = cfg["SN_eps"]
+    ye = F.embedding(y, sd["shared.weight"])                                    # :462
+    ye = linear(sd, "linear_f", torch.cat([ye, rdof], 1), training, se)         # :467
+    ye = rrm(sd, "RR_G", ye.unsqueeze(0), cfg.get("n_head_G", 2), training, se).squeeze(0)  # :468
+    zc = torch.cat([ye, z], 1)                                                  # :472
+    h = linear(sd, "linear", zc, training, se)                                  # :475
+    bw = cfg.get("bottom_width", 4)
+    h = h.view(h.size(0), -1, bw, bw * cfg.get("H_base", 1))                    # :477-479
+    for (s, g, cin, cout, up) in g_stages(cfg):
+        h = g_block(sd, f"blocks.{s * cfg.get('G_depth', 2) + g}.0", h, zc, cin, cout, up, training, cfg)
+    h = F.relu(plain_bn(sd, "output_layer.0", h, training, cfg["BN_eps"]))
+    return torch.tanh(conv(sd, "output_layer.2", h, training, se, 1))           # :487
+
+
+# --------------------------------------------------------------------------------------------
+# discriminator                                                  (model.py:534-557, 902-944)
+# --------------------------------------------------------------------------------------------
+def d_block(sd, p, x, cin, cout, down, preact, training, se):
+    h = F.relu(x) if preact else x                                               # :544-545
+    h = conv(sd, p + ".conv1", h, training, se, 0)
+    h = conv(sd, p + ".conv2", F.relu(h), training, se, 1)
+    h = conv(sd, p + ".conv3", F.relu(h), training, se, 1)
+    h = F.relu(h)
+    if down:
+        h = F.avg_pool2d(h, 2)
+    h = conv(sd, p + ".conv4", h, training, se, 0)
+    sc = F.avg_pool2d(x, 2) if down else x                                       # :534-539
+    if cin != cout:
+        sc = torch.cat([sc, conv(sd, p + ".conv_sc", sc, training, se, 0)], 1)
+    return h + sc
+
+
+def nonlocal_attention(sd, p, x, training, se):
+    """layers.Attention.forward (layers.py:283-300)."""
+    ch = x.shape[1]
+    N, _, H, W = x.shape
+    theta = conv(sd, p + ".theta", x, training, se, 0)
+    phi = F.max_pool2d(conv(sd, p + ".phi", x, training, se, 0), [2, 2])
+    g = F.max_pool2d(conv(sd, p + ".g", x, training, se, 0), [2, 2])
+    theta = theta.view(-1, ch // 8, H * W)
+    phi = phi.view(-1, ch // 8, H * W // 4)
+    g = g.view(-1, ch // 2, H * W // 4)
+    beta = F.softmax(torch.bmm(theta.transpose(1, 2), phi), -1)
+    o = conv(sd, p + ".o", torch.bmm(g, beta.transpose(1, 2)).view(-1, ch // 2, H, W), training, se, 0)
+    return sd[p + ".gamma"] * o + x
+
+
+def discriminator(sd: State, cfg, x: Tensor, y: Tensor, training: bool = True):
+    """model.Discriminator.forward (model.py:902-944); Contra (+RRM_embed) or Proj head."""
+    se = cfg["SN_eps"]
+    depth = cfg.get("D_depth", 2)
+    h = conv(sd, "input_conv", x, training, se, 1)
+    for (s, d, cin, cout, down, preact, attn) in d_stages(cfg):
+        h = d_block(sd, f"blocks.{s}.{d}", h, cin, cout, down, preact, training, se)
+        if attn:
+            h = nonlocal_attention(sd, f"blocks.{s}.{depth}", h, training, se)
+    h = torch.sum(F.relu(h), [2, 3])                                             # :912
+    if cfg["conditional_strategy"] == "Contra":
+        out = torch.squeeze(linear(sd, "linear0", h, training, se))             # :915
+        proxy = embedding(sd, "embed", y, training, se)                          # :916
+        if cfg.get("RRM_embed", False):
+            h = rrm(sd, "RR_D", h.unsqueeze(0), cfg.get("n_head_D", 4), training, se).squeeze(0)
+            e = linear(sd, "linear1", h, training, se)
+            e = F.layer_norm(e, (e.shape[-1],), sd["norm.weight"], sd["norm.bias"], 1e-5)
+        else:
+            e = linear(sd, "linear1", h, training, se)
+        if cfg.get("normalize_embed", True):
+            proxy, e = F.normalize(proxy, dim=1), F.normalize(e, dim=1)          # :933-935
+        return proxy, e, out
+    out = linear(sd, "linear0", h, training, se)                                 # :941-943 (Proj)
+    return out + torch.sum(embedding(sd, "embed", y, training, se) * h, 1, keepdim=True)
+
+
+# --------------------------------------------------------------------------------------------
+# augmentation                                             (diff_aug.py:10-109, cr_diff_aug.py:11-63)
+# --------------------------------------------------------------------------------------------
+def diffaug_draws(n: int, h: int, w: int, device="cpu", generator=None) -> Dict[str, Tensor]:
+    """The seven draws of DiffAugment('color,translation,cutout'), in the reference's call order
+    (diff_aug.py:24-26, 32-34, 40-42, 50-55, 74-85) so that a seeded global generator replays it."""
+    kw = dict(device=device, generator=generator)
+    sh_x, sh_y = int(h * 0.125 + 0.5), int(w * 0.125 + 0.5)
+    cs = int(h * 0.5 + 0.5), int(w * 0.5 + 0.5)
+    d = {}
+    d["brightness"] = torch.rand(n, 1, 1, 1, **kw)
+    d["saturation"] = torch.rand(n, 1, 1, 1, **kw)
+    d["contrast"] = torch.rand(n, 1, 1, 1, **kw)
+    d["tx"] = torch.randint(-sh_x, sh_x + 1, size=[n, 1, 1], **kw)
+    d["ty"] = torch.randint(-sh_y, sh_y + 1, size=[n, 1, 1], **kw)
+    d["ox"] = torch.randint(0, h + (1 - cs[0] % 2), size=[n, 1, 1], **kw)
+    d["oy"] = torch.randint(0, w + (1 - cs[1] % 2), size=[n, 1, 1], **kw)
+    return d
+
+
+def diff_augment(x: Tensor, d: Dict[str, Tensor]) -> Tensor:
+    """DiffAugment(x, 'color,translation,cutout') on NCHW with explicit draws ``d``."""
+    N, C, H, W = x.shape
+    x = x + (d["brightness"].view(N, 1, 1, 1) - 0.5)                              # :23-27
+    m = x.mean(dim=1, keepdim=True)
+    x = (x - m) * (d["saturation"].view(N, 1, 1, 1) * 2) + m                      # :30-35
+    m = x.mean(dim=[1, 2, 3], keepdim=True)
+    x = (x - m) * (d["contrast"].view(N, 1, 1, 1) + 0.5) + m                      # :38-43
+    # translation with zero fill (:46-69): out[h, w] = x[h + tx, w + ty] when inside, else 0
+    hh = torch.arange(H).view(1, H, 1) + d["tx"].view(N, 1, 1)
+    ww = torch.arange(W).view(1, 1, W) + d["ty"].view(N, 1, 1)
+    inside = ((hh >= 0) & (hh < H) & (ww >= 0) & (ww < W)).unsqueeze(1)
+    hh, ww = hh.clamp(0, H - 1), ww.clamp(0, W - 1)
+    idx = (hh * W + ww).view(N, 1, H * W).expand(N, C, H * W)
+    x = torch.gather(x.reshape(N, C, H * W), 2, idx).view(N, C, H, W) * inside
+    # cutout (:72-102): rows clamp(i + ox - ch//2), i in [0, ch) are zeroed (same for columns)
+    ch_, cw_ = int(H * 0.5 + 0.5), int(W * 0.5 + 0.5)
+    r0 = (d["ox"].view(N, 1, 1) - ch_ // 2).clamp(0, H - 1)
+    r1 = (d["ox"].view(N, 1, 1) - ch_ // 2 + ch_ - 1).clamp(0, H - 1)
+    c0 = (d["oy"].view(N, 1, 1) - cw_ // 2).clamp(0, W - 1)
+    c1 = (d["oy"].view(N, 1, 1) - cw_ // 2 + cw_ - 1).clamp(0, W - 1)
+    rr, cc = torch.arange(H).view(1, H, 1), torch.arange(W).view(1, 1, W)
+    cut = (rr >= r0) & (rr <= r1) & (cc >= c0) & (cc <= c1)
+    return (x * (~cut).unsqueeze(1).to(x.dtype)).contiguous()
+
+
+def cr_draws(n: int, h: int, w: int, device="cpu", generator=None) -> Dict[str, Tensor]:
+    """Draw order of CR_DiffAug: CPU uniform for the flip (cr_diff_aug.py:24), then t_x, t_y."""
+    d = {"flip": torch.rand(n, 1, generator=generator)}       # FloatTensor(n,1).uniform_(0,1)
+    d["tx"] = torch.randint(-int(h / 8), int(h / 8) + 1, size=[n, 1, 1], device=device, generator=generator)
+    d["ty"] = torch.randint(-int(w / 8), int(w / 8) + 1, size=[n, 1, 1], device=device, generator=generator)
+    return d
+
+
+def _reflect(i: Tensor, n: int) -> Tensor:
+    i = i.abs()
+    return torch.where(i >= n, 2 * (n - 1) - i, i)
+
+
+def cr_diff_augment(x: Tensor, d: Dict[str, Tensor]) -> Tensor:
+    """CR_DiffAug(x): per-image horizontal flip (p=.5) then reflect-padded translation."""
+    N, C, H, W = x.shape
+    flip = (d["flip"].view(N) < 0.5).view(N, 1, 1, 1)                               # :21-35
+    x = torch.where(flip, torch.flip(x, [3]), x)
+    hh = _reflect(torch.arange(H).view(1, H, 1) + d["tx"].view(N, 1, 1), H)        # :38-63
+    ww = _reflect(torch.arange(W).view(1, 1, W) + d["ty"].view(N, 1, 1), W)
+    idx = (hh * W + ww).view(N, 1, H * W).expand(N, C, H * W)
+    return torch.gather(x.reshape(N, C, H * W), 2, idx).view(N, C, H, W).contiguous()
+
+
+# --------------------------------------------------------------------------------------------
+# losses                                                                       (loss.py:8-44, 79-132)
+# --------------------------------------------------------------------------------------------
+def unif_loss(x: Tensor, t: float = 2.0) -> Tensor:
+    return torch.pdist(x, p=2).pow(2).mul(-t).exp().mean().log()                  # loss.py:8-9
+
+
+def iea_loss(k_f: Tensor, k_r: Tensor) -> Tensor:
+    with torch.no_grad():                                                         # loss.py:14-27
+        tgt = F.softmax(k_r @ k_r.t(), dim=-1)
+    logp = F.log_softmax(k_f @ k_f.t(), dim=-1)
+    return F.kl_div(logp, tgt, reduction="batchmean")
+
+
+def hinge_dis(d_fake: Tensor, d_real: Tensor) -> Tuple[Tensor, Tensor]:
+    return torch.mean(F.relu(1.0 - d_real)), torch.mean(F.relu(1.0 + d_fake))     # loss.py:30-33
+
+
+def hinge_gen(d_fake: Tensor) -> Tensor:
+    return -torch.mean(d_fake)                                                    # loss.py:36-38
+
+
+def l2_loss(a: Tensor, b: Tensor) -> Tensor:
+    return F.mse_loss(a, b)                                                       # loss.py:41-44
+
+
+def contrastive_loss(embed: Tensor, proxy: Tensor, temperature: float = 1.0, margin: float = 0.0) -> Tensor:
+    """Conditional_Contrastive_loss.forward with pos_collected_numerator=False (loss.py:103-132)."""
+    n = embed.shape[0]
+    sim = F.cosine_similarity(embed.unsqueeze(1), embed.unsqueeze(0), dim=-1)
+    off = ~torch.eye(n, dtype=torch.bool)
+    zone = torch.exp((sim[off].view(n, n - 1) - margin) / temperature)
+    pos = torch.exp((F.cosine_similarity(embed, proxy, dim=-1) - margin) / temperature)
+    den = torch.cat([pos.unsqueeze(1), zone], 1).sum(1)
+    return -torch.log(temperature * (pos / den)).mean()
+
+
+# --------------------------------------------------------------------------------------------
+# optimiser-side pieces                          (utils/__init__.py:809-859, model.py:410-416)
+# --------------------------------------------------------------------------------------------
+def ortho_grad(W: Tensor, strength: float = 1e-4) -> Tensor:
+    """Term added to ``param.grad`` by utils.ortho (utils/__init__.py:852-858)."""
+    w = W.reshape(W.shape[0], -1)
+    g = 2 * torch.mm(torch.mm(w, w.t()) * (1.0 - torch.eye(w.shape[0])), w)
+    return strength * g.view(W.shape)
+
+
+def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr, b1, b2, eps) -> None:
+    """torch.optim.Adam single-tensor update (no amsgrad, no weight decay), in place."""
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+    p.addcdiv_(m, (v.sqrt() / math.sqrt(bc2)).add_(eps), value=-lr / bc1)
+
+
+def ema_update(target: State, source: State, itr: Optional[int], decay=0.9999, start_itr=0) -> None:
+    """apply_ema.update over every state-dict entry (utils/__init__.py:825-837)."""
+    d = 0.0 if (itr and itr < start_itr) else decay
+    with torch.no_grad():
+        for k in source:
+            target[k].copy_(target[k] * d + source[k] * (1 - d))
+
+
+# --------------------------------------------------------------------------------------------
+# the train step                                                           (train_fns.py:20-206)
+# --------------------------------------------------------------------------------------------
+def g_param_names(sd: State):
+    return [k for k in sd if sd[k].requires_grad]
+
+
+def _set_requires_grad(sd: State, names, flag: bool):
+    for k in names:
+        sd[k].requires_grad_(flag)
+
+
+class TrainState:
+    """Parameters / buffers / Adam state of G and D held as plain dicts (no nn.Module)."""
+
+    def __init__(self, g_sd: State, d_sd: State, g_params, d_params, cfg):
+        self.g, self.d, self.cfg = g_sd, d_sd, cfg
+        self.g_params, self.d_params = list(g_params), list(d_params)
+        self.g_adam = {k: [torch.zeros_like(g_sd[k]), torch.zeros_like(g_sd[k])] for k in self.g_params}
+        self.d_adam = {k: [torch.zeros_like(d_sd[k]), torch.zeros_like(d_sd[k])] for k in self.d_params}
+        self.g_step = 0
+        self.d_step = 0
+        self.ema: Optional[State] = None
+
+
+def train_step(ts: TrainState, x: Tensor, y: Tensor, noise: dict, itr: int = 1) -> Dict[str, float]:
+    """One D update + one G update (train_fns.py:23-205, Contra branch, split_D, no Con_reg).
+
+    ``noise`` = {'z_d','rdof_d','aug_d' (dict|None), 'z_g','rdof_g','aug_g'}: the explicit draws of
+    the D-phase and G-phase generator passes.  Config keys used: contra_lambda, IEA_loss/IEA_lambda,
+    Uniformity_loss/unif_lambda, diff_aug, G_ortho, clip_norm, ema.  Terms switched off contribute
+    0.0 to the returned dict (the reference raises UnboundLocalError there).
+    ``clip_norm=None`` reproduces the reference quirk that G's optimiser never steps (9-Q1)."""
+    cfg, g, d = ts.cfg, ts.g, ts.d
+    zero = torch.zeros(())
+    # ---------------- D phase (train_fns.py:41-139)
+    _set_requires_grad(d, ts.d_params, True)
+    _set_requires_grad(g, ts.g_params, False)
+    with torch.no_grad():                                                          # model.py:973-978
+        gz = generator(g, cfg, noise["z_d"], y, noise["rdof_d"], True)
+        if cfg.get("diff_aug", True):
+            gz = diff_augment(gz, noise["aug_d"])
+    proxy_f, emb_f, d_fake = discriminator(d, cfg, gz, y, True)                    # model.py:987
+    proxy_r, emb_r, d_real = discriminator(d, cfg, x, y, True)                     # model.py:1002
+    l_real, l_fake = hinge_dis(d_fake, d_real)
+    d_loss = l_real + l_fake
+    if cfg.get("contra_lambda", 1.0) != 0:
+        d_loss = d_loss + cfg["contra_lambda"] * contrastive_loss(emb_r, proxy_r)
+    unif_d = zero
+    if cfg.get("Uniformity_loss", False):
+        unif_d = unif_loss(emb_r)
+        d_loss = d_loss + cfg["unif_lambda"] * unif_d
+    grads = torch.autograd.grad(d_loss, [d[k] for k in ts.d_params], allow_unused=True)
+    d_grads = {k: (gr if gr is not None else torch.zeros_like(d[k])) for k, gr in zip(ts.d_params, grads)}
+    if cfg.get("clip_norm") is not None:
+        _clip(d_grads, cfg["clip_norm"])
+    ts.d_step += 1
+    with torch.no_grad():
+        for k in ts.d_params:
+            adam_step(d[k], d_grads[k], *ts.d_adam[k], ts.d_step, cfg["D_lr"], cfg["D_B1"], cfg["D_B2"], cfg["adam_eps"])
+    # ---------------- G phase (train_fns.py:142-192)
+    _set_requires_grad(d, ts.d_params, False)
+    _set_requires_grad(g, ts.g_params, True)
+    gz = generator(g, cfg, noise["z_g"], y, noise["rdof_g"], True)
+    if cfg.get("diff_aug", True):
+        gz = diff_augment(gz, noise["aug_g"])
+    proxy_f, emb_f, d_fake = discriminator(d, cfg, gz, y, True)
+    g_loss = hinge_gen(d_fake)
+    if cfg.get("contra_lambda", 1.0) != 0:
+        g_loss = g_loss + cfg["contra_lambda"] * contrastive_loss(emb_f, proxy_f)
+    iea = zero
+    if cfg.get("IEA_loss", False):
+        iea = iea_loss(emb_f, emb_r.detach())
+        g_loss = g_loss + cfg["IEA_lambda"] * iea
+        if cfg.get("Uniformity_loss", False):                                      # nested, :171-178
+            g_loss = g_loss + cfg["unif_lambda"] * unif_loss(emb_f)
+    grads = torch.autograd.grad(g_loss, [g[k] for k in ts.g_params], allow_unused=True)
+    g_grads = {k: (gr if gr is not None else torch.zeros_like(g[k])) for k, gr in zip(ts.g_params, grads)}
+    if cfg.get("G_ortho", 0.0) > 0.0:                                              # :185-188
+        for k in ts.g_params:
+            if g[k].dim() >= 2 and k != "shared.weight":
+                g_grads[k] = g_grads[k] + ortho_grad(g[k].detach(), cfg["G_ortho"])
+    if cfg.get("clip_norm") is not None:                                           # :190-192
+        _clip(g_grads, cfg["clip_norm"])
+        ts.g_step += 1
+        with torch.no_grad():
+            for k in ts.g_params:
+                adam_step(g[k], g_grads[k], *ts.g_adam[k], ts.g_step, cfg["G_lr"], cfg["G_B1"], cfg["G_B2"], cfg["adam_eps"])
+    if cfg.get("ema", False) and ts.ema is not None:
+        ema_update(ts.ema, {k: v.detach() for k, v in g.items()}, itr, cfg["ema_decay"], cfg["ema_start"])
+    ts.last_grads = (g_grads, d_grads)
+    return {"G_loss": float(g_loss), "D_loss_real": float(l_real), "D_loss_fake": float(l_fake),
+            "unif_loss_d": float(unif_d), "iea_loss": float(iea)}
+
+
+def _clip(grads: Dict[str, Tensor], max_norm: float) -> None:
+    """torch.nn.utils.clip_grad_norm_ (L2, error_if_nonfinite=False)."""
+    total = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g) for g in grads.values()]))
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    for g in grads.values():
+        g.mul_(coef)
+
+
+# --------------------------------------------------------------------------------------------
+# export step after the path                                   (model.py:1130-1148)
+# --------------------------------------------------------------------------------------------
+def generate_export(img: Tensor) -> Tensor:
+    img = F.threshold(img, -0.26, -1)
+    img = img * 0.5 + 0.5
+    img = torch.pow(256, img).add(-1).clamp(0, 255)
+    return img[:, 0, 3:-3, :]
+
+
+# --------------------------------------------------------------------------------------------
+# state-dict contract + platform-independent synthetic weights (test scaffolding)
+# --------------------------------------------------------------------------------------------
+_BUFFER_LEAVES = ("u0", "sv0", "stored_mean", "stored_var")
+
+
+def is_buffer(key: str) -> bool:
+    return key.rsplit(".", 1)[-1] in _BUFFER_LEAVES
+
+
+def _sn(spec, p, out_f, in_shape, bias=True, sn=True, n_u=None):
+    spec[p + ".weight"] = (out_f,) + tuple(in_shape)
+    if bias:
+        spec[p + ".bias"] = (out_f,)
+    if sn:
+        spec[p + ".u0"] = (1, n_u if n_u is not None else out_f)
+        spec[p + ".sv0"] = (1,)
+
+
+def _rrm_spec(spec, p, dim, ff, sn):
+    q = p + ".layers.0"
+    _sn(spec, q + ".self_attn.qkv_proj", 3 * dim, (dim,), sn=sn)
+    _sn(spec, q + ".self_attn.o_proj", dim, (dim,), sn=sn)
+    _sn(spec, q + ".linear_net.0", ff, (dim,), sn=sn)
+    _sn(spec, q + ".linear_net.3", dim, (ff,), sn=sn)
+    for nm in (q + ".norm1", q + ".norm2", p + ".norm"):
+        spec[nm + ".weight"] = (dim,)
+        spec[nm + ".bias"] = (dim,)
+
+
+def g_spec(cfg) -> Dict[str, tuple]:
+    """Key -> shape of model.Generator(**cfg).state_dict() (model.py:283-387)."""
+    spec: Dict[str, tuple] = {}
+    sd_, dz = cfg.get("shared_dim", 128), cfg.get("dim_z", 128)
+    cond = sd_ + dz
+    spec["shared.weight"] = (cfg["n_classes"], sd_)
+    _sn(spec, "linear_f", 128, (sd_ + cfg.get("rdof_dim", 4),))
+    _rrm_spec(spec, "RR_G", 128, 128, sn=False)
+    stages = g_stages(cfg)
+    bw = cfg.get("bottom_width", 4)
+    _sn(spec, "linear", stages[0][2] * bw * bw * cfg.get("H_base", 1), (cond,))
+    for (s, g, cin, cout, up) in stages:
+        p = f"blocks.{s * cfg.get('G_depth', 2) + g}.0"
+        hid = cin // 4
+        _sn(spec, p + ".conv1", hid, (cin, 1, 1))
+        _sn(spec, p + ".conv2", hid, (hid, 3, 3))
+        _sn(spec, p + ".conv3", hid, (hid, 3, 3))
+        _sn(spec, p + ".conv4", cout, (hid, 1, 1))
+        for i, c in enumerate((cin, hid, hid, hid), 1):
+            q = f"{p}.bn{i}"
+            spec[q + ".stored_mean"] = (c,)
+            spec[q + ".stored_var"] = (c,)
+            _sn(spec, q + ".gain", c, (cond,), bias=False)
+            _sn(spec, q + ".bias", c, (cond,), bias=False)
+    c_last = stages[-1][3]
+    for leaf in ("gain", "bias", "stored_mean", "stored_var"):
+        spec["output_layer.0." + leaf] = (c_last,)
+    _sn(spec, "output_layer.2", 1, (c_last, 3, 3))
+    return spec
+
+
+def d_spec(cfg) -> Dict[str, tuple]:
+    """Key -> shape of model.Discriminator(**cfg).state_dict() (model.py:728-838), Contra head."""
+    spec: Dict[str, tuple] = {}
+    depth = cfg.get("D_depth", 2)
+    stages = d_stages(cfg)
+    _sn(spec, "input_conv", stages[0][2], (1, 3, 3))
+    for (s, d, cin, cout, down, preact, attn) in stages:
+        p = f"blocks.{s}.{d}"
+        hid = cout // 4
+        _sn(spec, p + ".conv1", hid, (cin, 1, 1))
+        _sn(spec, p + ".conv2", hid, (hid, 3, 3))
+        _sn(spec, p + ".conv3", hid, (hid, 3, 3))
+        _sn(spec, p + ".conv4", cout, (hid, 1, 1))
+        if cin != cout:
+            _sn(spec, p + ".conv_sc", cout - cin, (cin, 1, 1))
+        if attn:
+            a = f"blocks.{s}.{depth}"
+            spec[a + ".gamma"] = ()
+            _sn(spec, a + ".theta", cout // 8, (cout, 1, 1), bias=False)
+            _sn(spec, a + ".phi", cout // 8, (cout, 1, 1), bias=False)
+            _sn(spec, a + ".g", cout // 2, (cout, 1, 1), bias=False)
+            _sn(spec, a + ".o", cout, (cout // 2, 1, 1), bias=False)
+    c_top = stages[-1][3]
+    hyp = cfg.get("hypersphere_dim", 512)
+    _sn(spec, "linear0", 1, (c_top,))
+    if cfg["conditional_strategy"] == "Contra":
+        if cfg.get("RRM_embed", False):
+            _rrm_spec(spec, "RR_D", c_top, 512, sn=True)
+            spec["norm.weight"] = (hyp,)
+            spec["norm.bias"] = (hyp,)
+        _sn(spec, "linear1", hyp, (c_top,))
+        _sn(spec, "embed", cfg["n_classes"], (hyp,), bias=False, n_u=cfg["n_classes"])
+    else:
+        _sn(spec, "embed", cfg["n_classes"], (c_top,), bias=False, n_u=cfg["n_classes"])
+    return spec
+
+
+def synth_state(spec: Dict[str, tuple], seed: int) -> State:
+    """Deterministic, platform-independent weights: every entry is drawn from its own numpy PCG64
+    stream keyed by (seed, crc32(name)); scales keep activations O(1).  Not an initialiser of the
+    reference -- only a way to put *identical* numbers into the reference, this oracle and the
+    HIP path on any machine without shipping multi-MB weight files."""
+    import zlib
+    import numpy as np
+    out: State = {}
+    for k, shape in spec.items():
+        rng = np.random.Generator(np.random.PCG64([seed, zlib.crc32(k.encode())]))
+        leaf = k.rsplit(".", 1)[-1]
+        n = int(np.prod(shape)) if len(shape) else 1
+        a = rng.standard_normal(n).astype(np.float32).reshape(shape)
+        if leaf == "weight" and len(shape) >= 2:
+            fan_in = int(np.prod(shape[1:]))
+            a *= 1.0 / math.sqrt(fan_in)
+        elif leaf == "weight":                       # LayerNorm weight
+            a = 1.0 + 0.1 * a
+        elif leaf in ("bias",):
+            a *= 0.1
+        elif leaf == "gain" and len(shape) == 1:     # plain bn gain
+            a = 1.0 + 0.1 * a
+        elif leaf == "sv0":
+            a = np.ones(shape, np.float32)
+        elif leaf == "stored_mean":
+            a *= 0.05
+        elif leaf == "stored_var":
+            a = 1.0 + 0.05 * np.abs(a)
+        elif leaf == "gamma":
+            a = np.float32(0.5) * np.ones(shape, np.float32)
+        out[k] = torch.from_numpy(np.ascontiguousarray(a)).clone()
+    return out
+
+
+def synth_nets(cfg, seed_g: int, seed_d: int) -> Tuple[State, State]:
+    """Synthetic G and D states; D's logit bias is shifted so that the logits straddle 0 and both
+    hinge terms are active (with the raw draw every logit sits below -1)."""
+    g_state = synth_state(g_spec(cfg), seed_g)
+    d_state = synth_state(d_spec(cfg), seed_d)
+    d_state["linear0.bias"] += 3.9
+    return g_state, d_state
+
+
+def as_trainable(sd: State) -> Tuple[State, list]:
+    """Clone a state mapping into leaf tensors; parameters get requires_grad=True."""
+    out, params = {}, []
+    for k, v in sd.items():
+        t = v.detach().clone()
+        if not is_buffer(k):
+            t.requires_grad_(True)
+            params.append(k)
+        out[k] = t
+    return out, params
+
+
+def synth_event(n: int, h: int, w: int, seed: int) -> Tensor:
+    """Synthetic PXD-like event: background -1, ~1 % log-normalised hits, 4e-3 noise."""
+    import numpy as np
+    rng = np.random.Generator(np.random.PCG64([seed, 77]))
+    hit = rng.random((n, 1, h, w)) < 0.01
+    u = rng.uniform(0.03, 1.0, (n, 1, h, w))
+    img = np.where(hit, np.log(255.0 * u + 1.0) / math.log(256.0), 0.0)
+    img = img + 4e-3 * rng.random((n, 1, h, w))
+    return torch.from_numpy((2.0 * img - 1.0).astype(np.float32))
