@@ -288,8 +288,8 @@ def test_train_step_64(golden_dir, ref_cfg, tag, clip, moved):
     _close(gn, g["G_gradnorm"], tol=5e-4, what="G grad norms")
     _close(dn, g["D_gradnorm"], tol=5e-4, what="D grad norms")
     for name, sd, spec in (("G", gsd, O.g_spec(cfg)), ("D", dsd, O.d_spec(cfg))):
-        sums = torch.tensor([sd[k].double().sum().item() for k in spec])
-        asums = torch.tensor([sd[k].double().abs().sum().item() for k in spec])
+        sums = torch.tensor([sd[k].double().sum().item() for k in spec], dtype=torch.float64)
+        asums = torch.tensor([sd[k].double().abs().sum().item() for k in spec], dtype=torch.float64)
         assert torch.allclose(sums, g[f"{name}_sum"], rtol=1e-4, atol=1e-3), name
         assert torch.allclose(asums, g[f"{name}_abssum"], rtol=1e-4, atol=1e-3), name
     n_moved = sum(int(not torch.equal(gsd[k].detach(), g0[k])) for k in gp)
