@@ -1,0 +1,128 @@
+"""ctypes binding of libieagan_hip.so (the C ABI declared in include/ieagan_hip.h).
+
+There is deliberately NO fallback: if the shared object is missing or a kernel launcher reports an
+error, a RuntimeError is raised.  The product path never routes through PyTorch eager convolutions
+or through the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libieagan_hip.so")
+STAT_REPL = 32          # replicas of every (sum, sumsq) statistics buffer (common.h)
+SN_FIELDS = 16          # int64 fields per row of the spectral-norm layer table (sn.hip)
+
+vp, fp, lp, ip = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p   # all device pointers travel as void*
+
+
+class SrcDesc(C.Structure):
+    _fields_ = [("x", vp), ("Cx", C.c_int), ("Hs", C.c_int), ("Ws", C.c_int), ("rs", C.c_int),
+                ("scale", vp), ("shift", vp), ("aff_nstride", C.c_int), ("relu", C.c_int)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
+                ("taps", C.c_int), ("Kpad", C.c_int), ("src", SrcDesc), ("w", vp), ("bias", vp),
+                ("ra", vp), ("Cra", C.c_int), ("Ca", C.c_int), ("ra_rs", C.c_int), ("rb", vp),
+                ("Crb", C.c_int), ("mask", vp), ("out", vp), ("stats", vp)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
+                ("taps", C.c_int), ("Kpad", C.c_int), ("src", SrcDesc), ("g", vp), ("Cg", C.c_int),
+                ("dw", vp), ("tiles_per_block", C.c_int)]
+
+
+class ProfRec(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_long), ("ms", C.c_double),
+                ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+i, f, l = C.c_int, C.c_float, C.c_long
+_SIGS = {
+    "ieagan_abi_version": [],
+    "ieagan_prof_enable": [i],
+    "ieagan_prof_reset": [],
+    "ieagan_prof_collect": [C.POINTER(ProfRec), i],
+    "ieagan_conv_forward": [C.POINTER(ConvDesc), vp],
+    "ieagan_conv_wgrad": [C.POINTER(WgradDesc), i, vp],
+    "ieagan_effgrad": [vp, vp, vp, vp, vp, l, i, vp],
+    "ieagan_prologue_bwd": [vp, vp, i, vp, vp, i, i, i, vp, vp, vp, i, i, i, i, vp],
+    "ieagan_bn_finalize_fwd": [vp, f, vp, vp, i, i, f, f, i, vp, vp, vp, vp, vp, i, i, vp],
+    "ieagan_bn_finalize_bwd": [vp, vp, vp, i, i, vp, f, i, vp, vp, i, vp, i, i, vp],
+    "ieagan_res_bwd": [vp, i, vp, i, i, i, i, i, i, vp],
+    "ieagan_nchw_to_nhwc": [vp, vp, vp, i, i, i, vp],
+    "ieagan_nhwc_to_nchw": [vp, vp, i, i, i, vp],
+    "ieagan_channel_stats": [vp, vp, l, i, vp],
+    "ieagan_conv_1toC": [vp, vp, vp, vp, vp, i, i, i, i, i, vp],
+    "ieagan_conv_Cto1": [vp, vp, vp, i, i, vp, vp, vp, i, i, i, i, i, i, vp],
+    "ieagan_wgrad_c1": [vp, vp, vp, vp, vp, i, i, vp, i, i, i, i, i, vp],
+    "ieagan_sn_forward": [vp, vp, i, vp, vp, vp, f, i, vp],
+    "ieagan_sn_backward": [vp, vp, i, i, i, i, i, i, vp, vp, vp, vp],
+    "ieagan_diffaug_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, vp],
+    "ieagan_diffaug_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, vp],
+    "ieagan_cr_diffaug": [vp, vp, vp, vp, vp, i, i, i, vp],
+    "ieagan_adam_step": [vp, vp, vp, vp, l, f, f, f, f, i, f, vp],
+    "ieagan_ema_update": [vp, vp, l, f, vp],
+    "ieagan_selftest_tr_read": [vp, vp, vp],
+}
+EXPORTS = ["ieagan_last_error"] + list(_SIGS)
+
+_lib = None
+
+
+def lib():
+    """Load the shared object once (after torch, so that it binds to torch's HIP runtime)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(iea-gan_amd/csrc/build.sh).  There is no PyTorch/CPU fallback for the MI355X path.")
+        _lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        _lib.ieagan_last_error.restype = C.c_char_p
+        for name, sig in _SIGS.items():
+            fn = getattr(_lib, name)
+            fn.argtypes = sig
+            fn.restype = C.c_int
+    return _lib
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("the IEA-GAN MI355X path needs a HIP device (torch.cuda.is_available() is False); "
+                           "there is no CPU fallback -- use oracle/ only as a test checker")
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+def call(name: str, *args) -> None:
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {lib().ieagan_last_error().decode()}")
+
+
+# ---- small helpers shared by the op layer ----------------------------------------------------------
+def src_desc(x, Cx, Hs, Ws, rs=0, scale=None, shift=None, nstride=0, relu=False) -> SrcDesc:
+    return SrcDesc(ptr(x), Cx, Hs, Ws, rs, ptr(scale), ptr(shift), nstride, int(bool(relu)))
+
+
+def prof_enable(on: bool) -> None:
+    call("ieagan_prof_enable", int(on))
+
+
+def prof_collect() -> list:
+    buf = (ProfRec * 64)()
+    n = lib().ieagan_prof_collect(buf, 64)
+    return [dict(name=buf[k].name.decode(), launches=buf[k].launches, ms=buf[k].ms, flops=buf[k].flops,
+                 bytes=buf[k].bytes) for k in range(n)]

@@ -1,0 +1,211 @@
+// Coalesced element-wise kernels on fp32 single-channel events and on the flat parameter arena:
+//   DiffAugment 'color,translation,cutout' forward / backward  (diff_aug.py:10-109)
+//   CR_DiffAug flip + reflect translation                       (cr_diff_aug.py:11-63)
+//   Adam (no amsgrad / weight decay) on the flat arena          (model.py:410-416, 858-864)
+//   EMA over the whole flat state                               (utils/__init__.py:825-837)
+#include "common.h"
+
+// per-image sums: out[n] += sum_hw f(x)
+//   MODE 0: f = x                                   (mean for rand_contrast)
+//   MODE 1: f = gout at positions that survive translation + cutout (mean term of the backward)
+struct AugDraws {
+    const float* bright;   // [N] uniform
+    const float* contrast; // [N] uniform
+    const long* tx;        // [N]
+    const long* ty;
+    const long* ox;
+    const long* oy;
+};
+
+__device__ __forceinline__ bool aug_keep(int h, int w, int H, int W, int tx, int ty, int ox, int oy) {
+    // output pixel (h,w) reads source (h+tx, w+ty); zero when that is outside or (h,w) is cut out
+    const int hs = h + tx, ws = w + ty;
+    if (hs < 0 || hs >= H || ws < 0 || ws >= W) return false;
+    const int ch = (H + 1) / 2 - ((H % 2) ? 0 : 0);  // int(H*0.5+0.5)
+    return true & (ch >= 0);
+}
+
+__device__ __forceinline__ bool in_cut(int h, int w, int H, int W, int ox, int oy) {
+    const int ch = (int)(H * 0.5f + 0.5f), cw = (int)(W * 0.5f + 0.5f);
+    int r0 = ox - ch / 2, r1 = ox - ch / 2 + ch - 1;
+    int c0 = oy - cw / 2, c1 = oy - cw / 2 + cw - 1;
+    r0 = max(0, min(r0, H - 1));
+    r1 = max(0, min(r1, H - 1));
+    c0 = max(0, min(c0, W - 1));
+    c1 = max(0, min(c1, W - 1));
+    return h >= r0 && h <= r1 && w >= c0 && w <= c1;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void aug_sum_kernel(const float* __restrict__ x, AugDraws d, float* __restrict__ out, int H, int W) {
+    __shared__ float red[4];
+    const int n = blockIdx.y;
+    const long HW = (long)H * W;
+    const float* xi = x + (long)n * HW;
+    int tx = 0, ty = 0, ox = 0, oy = 0;
+    if (MODE == 1) {
+        tx = (int)d.tx[n]; ty = (int)d.ty[n]; ox = (int)d.ox[n]; oy = (int)d.oy[n];
+    }
+    float s = 0.f;
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
+        float v = xi[p];
+        if (MODE == 1) {
+            const int h = (int)(p / W), w = (int)(p - (long)h * W);
+            const int hs = h + tx, ws = w + ty;
+            if (hs < 0 || hs >= H || ws < 0 || ws >= W || in_cut(h, w, H, W, ox, oy)) v = 0.f;
+        }
+        s += v;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out + n, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void diffaug_fwd_kernel(const float* __restrict__ x, AugDraws d, const float* __restrict__ sums,
+                                                          float* __restrict__ out, int H, int W) {
+    const int n = blockIdx.y;
+    const long HW = (long)H * W;
+    const float b = d.bright[n] - 0.5f, c = d.contrast[n] + 0.5f;
+    const float m = sums[n] / (float)HW + b;          // mean of the brightened image
+    const int tx = (int)d.tx[n], ty = (int)d.ty[n], ox = (int)d.ox[n], oy = (int)d.oy[n];
+    const float* xi = x + (long)n * HW;
+    float* oi = out + (long)n * HW;
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
+        const int h = (int)(p / W), w = (int)(p - (long)h * W);
+        const int hs = h + tx, ws = w + ty;
+        float v = 0.f;
+        if (hs >= 0 && hs < H && ws >= 0 && ws < W && !in_cut(h, w, H, W, ox, oy)) {
+            const float xb = xi[(long)hs * W + ws] + b;
+            v = (xb - m) * c + m;
+        }
+        oi[p] = v;
+    }
+}
+
+// gx[q] = c * g'(q) + (1-c) * mean(g'),  g'(q) = gout[q - t] if that output pixel exists and is kept
+__global__ __launch_bounds__(256) void diffaug_bwd_kernel(const float* __restrict__ gout, AugDraws d, const float* __restrict__ gsums,
+                                                          float* __restrict__ gx, int H, int W) {
+    const int n = blockIdx.y;
+    const long HW = (long)H * W;
+    const float c = d.contrast[n] + 0.5f;
+    const float mterm = (1.f - c) * gsums[n] / (float)HW;
+    const int tx = (int)d.tx[n], ty = (int)d.ty[n], ox = (int)d.ox[n], oy = (int)d.oy[n];
+    const float* gi = gout + (long)n * HW;
+    float* oi = gx + (long)n * HW;
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
+        const int hs = (int)(p / W), ws = (int)(p - (long)hs * W);
+        const int h = hs - tx, w = ws - ty;
+        float v = 0.f;
+        if (h >= 0 && h < H && w >= 0 && w < W && !in_cut(h, w, H, W, ox, oy)) v = gi[(long)h * W + w];
+        oi[p] = c * v + mterm;
+    }
+}
+
+static inline dim3 img_grid(int N, long HW) {
+    long b = (HW + 255) / 256;
+    if (b > 256) b = 256;
+    return dim3((unsigned)b, N);
+}
+
+extern "C" int ieagan_diffaug_fwd(const float* x, const float* bright, const float* contrast, const long* tx, const long* ty,
+                                  const long* ox, const long* oy, float* sums /*[N] zeroed*/, float* out, int N, int H, int W,
+                                  void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    AugDraws d{bright, contrast, tx, ty, ox, oy};
+    ProfScope prof("diffaug_fwd", 0.0, 12.0 * N * H * W, st);
+    hipLaunchKernelGGL((aug_sum_kernel<0>), img_grid(N, (long)H * W), dim3(256), 0, st, x, d, sums, H, W);
+    hipLaunchKernelGGL(diffaug_fwd_kernel, img_grid(N, (long)H * W), dim3(256), 0, st, x, d, (const float*)sums, out, H, W);
+    CHECK_LAUNCH("diffaug_fwd");
+    return 0;
+}
+
+extern "C" int ieagan_diffaug_bwd(const float* gout, const float* contrast, const long* tx, const long* ty, const long* ox,
+                                  const long* oy, float* gsums /*[N] zeroed*/, float* gx, int N, int H, int W, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    AugDraws d{nullptr, contrast, tx, ty, ox, oy};
+    ProfScope prof("diffaug_bwd", 0.0, 12.0 * N * H * W, st);
+    hipLaunchKernelGGL((aug_sum_kernel<1>), img_grid(N, (long)H * W), dim3(256), 0, st, gout, d, gsums, H, W);
+    hipLaunchKernelGGL(diffaug_bwd_kernel, img_grid(N, (long)H * W), dim3(256), 0, st, gout, d, (const float*)gsums, gx, H, W);
+    CHECK_LAUNCH("diffaug_bwd");
+    return 0;
+}
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * (n - 1) - i : i;
+}
+
+__global__ __launch_bounds__(256) void cr_diffaug_kernel(const float* __restrict__ x, const float* __restrict__ flip_u,
+                                                         const long* __restrict__ tx, const long* __restrict__ ty,
+                                                         float* __restrict__ out, int H, int W) {
+    const int n = blockIdx.y;
+    const long HW = (long)H * W;
+    const bool flip = flip_u[n] < 0.5f;
+    const int sx = (int)tx[n], sy = (int)ty[n];
+    const float* xi = x + (long)n * HW;
+    float* oi = out + (long)n * HW;
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
+        const int h = (int)(p / W), w = (int)(p - (long)h * W);
+        const int hs = reflect_idx(h + sx, H);
+        int ws = reflect_idx(w + sy, W);
+        if (flip) ws = W - 1 - ws;
+        oi[p] = xi[(long)hs * W + ws];
+    }
+}
+
+extern "C" int ieagan_cr_diffaug(const float* x, const float* flip_u, const long* tx, const long* ty, float* out, int N, int H,
+                                 int W, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof("cr_diffaug", 0.0, 8.0 * N * H * W, st);
+    hipLaunchKernelGGL(cr_diffaug_kernel, img_grid(N, (long)H * W), dim3(256), 0, st, x, flip_u, tx, ty, out, H, W);
+    CHECK_LAUNCH("cr_diffaug");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// flat-arena optimiser kernels (float4 per lane)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long n, float lr_bc1, float b1, float b2, float eps,
+                                                   float inv_sqrt_bc2, float gscale) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= lr_bc1 * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    }
+}
+
+extern "C" int ieagan_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                                int step, float gscale, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    CHECK_ARG(step >= 1, "adam: step must be >= 1");
+    ProfScope prof("adam_step", 0.0, 28.0 * n, st);
+    const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
+    long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, n, (float)(lr / bc1), b1, b2, eps,
+                       (float)(1.0 / sqrt(bc2)), gscale);
+    CHECK_LAUNCH("adam_step");
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ tgt, const float* __restrict__ src, long n, float decay) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        tgt[i] = tgt[i] * decay + src[i] * (1.f - decay);
+}
+
+extern "C" int ieagan_ema_update(float* tgt, const float* src, long n, float decay, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof("ema_update", 0.0, 12.0 * n, st);
+    long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(ema_kernel, dim3((unsigned)blocks), dim3(256), 0, st, tgt, src, n, decay);
+    CHECK_LAUNCH("ema_update");
+    return 0;
+}

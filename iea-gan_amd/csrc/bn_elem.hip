@@ -1,0 +1,433 @@
+// Bandwidth-bound companions of the conv kernels (bf16 NHWC, 16 bytes = 8 channels per lane):
+//   effgrad        g_eff = dout + dsum[c] + 2*out*dsumsq[c]   (batch-stat path of BN folded into the
+//                  producer's out-grad) + per-channel column sums (bias grads)
+//   prologue_bwd   backward of the fused conv prologue (BN apply + ReLU + upsample/pool): dx and the
+//                  per-(n,c) reductions d scale / d shift
+//   bn_finalize    (sum, sumsq, gain(y), bias(y)) -> per-(n,c) scale/shift, running-stat update;
+//                  and its backward -> d gain, d bias, d sum, d sumsq
+//   res_bwd        gradient of the residual operand of the conv epilogue (2x2 sum / 0.25 expand)
+//   layout         NCHW fp32 <-> NHWC bf16 at the module boundary (+ statistics)
+// Replaces F.batch_norm / ccbn / relu / interpolate / AvgPool2d backward of the reference
+// (layers.py:656-689, 728-742; model.py:54-71, 541-557).
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// block-level reduction of 8 per-thread partials by channel group; thread t owns channel group
+// (t % groups); result is added into dst[replica][c] with float atomics.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void reduce_groups_atomic(float (&part)[8], int groups, float* dst, float* red /*[256][8]*/) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[t * 8 + i] = part[i];
+    __syncthreads();
+    for (int o = t; o < groups * 8; o += 256) {
+        const int g = o >> 3, i = o & 7;
+        float s = 0.f;
+        for (int u = g; u < 256; u += groups) s += red[u * 8 + i];
+        atomicAdd(dst + g * 8 + i, s);
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// effgrad: P pixels x C channels.  dstat = [2][C] (dsum, dsumsq) or nullptr.  colsum = [STAT_REPL][C].
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void effgrad_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ out,
+                                                      const float* __restrict__ dstat, bf16* __restrict__ geff,
+                                                      float* __restrict__ colsum, long P, int C) {
+    __shared__ float red[256 * 8];
+    const int groups = C >> 3;                 // divides 256 (C in {16..512}, multiple of 16 ... checked on host)
+    const int cg = threadIdx.x % groups;
+    const long chunks = P * groups;
+    float ds[8], dq[8], part[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        ds[i] = dstat ? dstat[cg * 8 + i] : 0.f;
+        dq[i] = dstat ? 2.f * dstat[C + cg * 8 + i] : 0.f;
+        part[i] = 0.f;
+    }
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < chunks; idx += (long)gridDim.x * 256) {
+        const bf16x8 d = *(const bf16x8*)(dout + idx * 8);
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = bf2f(d[i]);
+        if (dstat) {
+            const bf16x8 o = *(const bf16x8*)(out + idx * 8);
+            bf16x8 w;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                v[i] = v[i] + ds[i] + bf2f(o[i]) * dq[i];
+                w[i] = f2bf(v[i]);
+            }
+            *(bf16x8*)(geff + idx * 8) = w;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) part[i] += v[i];
+    }
+    if (colsum) reduce_groups_atomic(part, groups, colsum + (long)(blockIdx.x % STAT_REPL) * C, red);
+}
+
+extern "C" int ieagan_effgrad(const void* dout, const void* out, const float* dstat, void* geff, float* colsum,
+                              long P, int C, void* stream) {
+    CHECK_ARG(C % 8 == 0 && 256 % (C / 8) == 0, "effgrad: C=%d must be 8*2^k <= 2048", C);
+    CHECK_ARG(dstat == nullptr || (out != nullptr && geff != nullptr), "effgrad: dstat needs out and geff");
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof("effgrad", 0.0, (dstat ? 6.0 : 2.0) * P * C, st);
+    long blocks = (P * (C / 8) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(effgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16*)dout, (const bf16*)out,
+                       dstat, (bf16*)geff, colsum, P, C);
+    CHECK_LAUNCH("effgrad");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// prologue_bwd: iterate over SOURCE pixels of one image (grid.y = n).
+//   da  [N, H, W, C]    gradient w.r.t. the conv input (conv resolution)
+//   x   [N, Hs, Ws, Cx] the source the prologue read (channels [0,C))
+//   dx  [N, Hs, Ws, C]
+// ------------------------------------------------------------------------------------------------
+template <bool AFF, bool RELU, int RS>
+__global__ __launch_bounds__(256) void prologue_bwd_kernel(const bf16* __restrict__ da, const bf16* __restrict__ x, int Cx,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           int nstride, bf16* __restrict__ dx, float* __restrict__ dscale,
+                                                           float* __restrict__ dshift, int Hs, int Ws, int C) {
+    __shared__ float red[256 * 8];
+    const int n = blockIdx.y;
+    const int groups = C >> 3;
+    const int cg = threadIdx.x % groups;
+    const int H = (RS == 1) ? 2 * Hs : (RS == 2) ? Hs / 2 : Hs;
+    const int W = (RS == 1) ? 2 * Ws : (RS == 2) ? Ws / 2 : Ws;
+    float sc[8], sh[8], p_ds[8], p_dt[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        sc[i] = AFF ? scale[(long)n * nstride + cg * 8 + i] : 1.f;
+        sh[i] = AFF ? shift[(long)n * nstride + cg * 8 + i] : 0.f;
+        p_ds[i] = p_dt[i] = 0.f;
+    }
+    const long chunks = (long)Hs * Ws * groups;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < chunks; idx += (long)gridDim.x * 256) {
+        const long sp = idx / groups;        // source pixel within the image (idx % groups == cg)
+        const int hs = (int)(sp / Ws), ws = (int)(sp - (long)hs * Ws);
+        float d[8];
+        if (RS == 0) {
+            const bf16x8 v = *(const bf16x8*)(da + (((long)n * H + hs) * W + ws) * C + cg * 8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) d[i] = bf2f(v[i]);
+        } else if (RS == 1) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) d[i] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bf16x8 v = *(const bf16x8*)(da + (((long)n * H + 2 * hs + (q >> 1)) * W + 2 * ws + (q & 1)) * C + cg * 8);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) d[i] += bf2f(v[i]);
+            }
+        } else {
+            const bf16x8 v = *(const bf16x8*)(da + (((long)n * H + (hs >> 1)) * W + (ws >> 1)) * C + cg * 8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) d[i] = 0.25f * bf2f(v[i]);
+        }
+        const bf16x8 xv = *(const bf16x8*)(x + (((long)n * Hs + hs) * Ws + ws) * Cx + cg * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float xf = bf2f(xv[i]);
+            const float pre = AFF ? xf * sc[i] + sh[i] : xf;
+            float di = d[i];
+            if (RELU && !(pre > 0.f)) di = 0.f;
+            p_ds[i] += di * xf;
+            p_dt[i] += di;
+            o[i] = f2bf(AFF ? di * sc[i] : di);
+        }
+        *(bf16x8*)(dx + (((long)n * Hs + hs) * Ws + ws) * C + cg * 8) = o;
+    }
+    if (AFF) {
+        reduce_groups_atomic(p_ds, groups, dscale + (long)n * nstride, red);
+        reduce_groups_atomic(p_dt, groups, dshift + (long)n * nstride, red);
+    }
+}
+
+extern "C" int ieagan_prologue_bwd(const void* da, const void* x, int Cx, const float* scale, const float* shift,
+                                   int nstride, int relu, int rs, void* dx, float* dscale, float* dshift, int N, int Hs,
+                                   int Ws, int C, void* stream) {
+    CHECK_ARG(C % 8 == 0 && 256 % (C / 8) == 0, "prologue_bwd: C=%d unsupported", C);
+    CHECK_ARG(rs >= 0 && rs <= 2, "prologue_bwd: bad rs");
+    CHECK_ARG(rs != 2 || (Hs % 2 == 0 && Ws % 2 == 0), "prologue_bwd: pooled source needs even size");
+    CHECK_ARG(scale == nullptr || (shift && dscale && dshift), "prologue_bwd: affine needs shift/dscale/dshift");
+    hipStream_t st = (hipStream_t)stream;
+    const double px = (double)N * Hs * Ws * C;
+    ProfScope prof("prologue_bwd", 0.0, 2.0 * px * (rs == 1 ? 6.0 : rs == 2 ? 2.25 : 3.0), st);
+    long per = ((long)Hs * Ws * (C / 8) + 255) / 256;
+    if (per > 64) per = 64;
+    if (per < 1) per = 1;
+    dim3 grid((unsigned)per, N);
+    const bool aff = scale != nullptr;
+#define PB(A, R, S) hipLaunchKernelGGL((prologue_bwd_kernel<A, R, S>), grid, dim3(256), 0, st, (const bf16*)da, (const bf16*)x, Cx, \
+                                       scale, shift, nstride, (bf16*)dx, dscale, dshift, Hs, Ws, C)
+#define PB_RS(A, R)            \
+    if (rs == 0) PB(A, R, 0);  \
+    else if (rs == 1) PB(A, R, 1); \
+    else PB(A, R, 2)
+    if (aff && relu) { PB_RS(true, true); }
+    else if (aff) { PB_RS(true, false); }
+    else if (relu) { PB_RS(false, true); }
+    else { PB_RS(false, false); }
+#undef PB_RS
+#undef PB
+    CHECK_LAUNCH("prologue_bwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bn_finalize (one small block; C <= 512, N <= 64 images)
+//   stats     [STAT_REPL][2][C] replicated (sum, sumsq) of the normalised tensor, count = N*H*W
+//   gain/bias per-(n,c) conditional terms with row stride ld (ccbn: scale uses 1+gain) or per-channel
+//             parameters with ld == 0 (plain bn: scale uses gain)
+//   training: batch statistics + running-stat update (momentum, unbiased variance for the running
+//             update, as F.batch_norm); eval: running statistics
+// ------------------------------------------------------------------------------------------------
+__global__ void bn_finalize_fwd_kernel(const float* __restrict__ stats, float count, const float* __restrict__ gain,
+                                       const float* __restrict__ bias, int ld, int plus_one, float eps, float momentum,
+                                       int training, float* __restrict__ run_mean, float* __restrict__ run_var,
+                                       float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_rstd,
+                                       int N, int C) {
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+        float mean, var;
+        if (training) {
+            float s1 = 0.f, s2 = 0.f;
+            for (int r = 0; r < STAT_REPL; ++r) {
+                s1 += stats[(long)r * 2 * C + c];
+                s2 += stats[(long)r * 2 * C + C + c];
+            }
+            mean = s1 / count;
+            var = fmaxf(s2 / count - mean * mean, 0.f);
+            run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
+            run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * (count / fmaxf(count - 1.f, 1.f));
+        } else {
+            mean = run_mean[c];
+            var = run_var[c];
+        }
+        const float rstd = rsqrtf(var + eps);
+        mean_rstd[c] = mean;
+        mean_rstd[C + c] = rstd;
+        const int rows = (ld == 0) ? 1 : N;
+        for (int n = 0; n < rows; ++n) {
+            const float g = gain[(long)n * ld + c] + (plus_one ? 1.f : 0.f);
+            const float s = rstd * g;
+            scale[(long)n * C + c] = s;
+            shift[(long)n * C + c] = bias[(long)n * ld + c] - mean * s;
+        }
+    }
+}
+
+extern "C" int ieagan_bn_finalize_fwd(const float* stats, float count, const float* gain, const float* bias, int ld,
+                                      int plus_one, float eps, float momentum, int training, float* run_mean,
+                                      float* run_var, float* scale, float* shift, float* mean_rstd, int N, int C,
+                                      void* stream) {
+    CHECK_ARG(!training || stats != nullptr, "bn_finalize: training mode needs batch statistics");
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof("bn_finalize_fwd", 0.0, 0.0, st);
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, stats, count, gain, bias, ld, plus_one, eps,
+                       momentum, training, run_mean, run_var, scale, shift, mean_rstd, N, C);
+    CHECK_LAUNCH("bn_finalize_fwd");
+    return 0;
+}
+
+//   dscale/dshift [rows][C]  ->  dgain/dbias [rows][ld-strided slice] (ld==0: [C]), dstat [2][C]
+__global__ void bn_finalize_bwd_kernel(const float* __restrict__ dscale, const float* __restrict__ dshift,
+                                       const float* __restrict__ gain, int ld, int plus_one, const float* __restrict__ mean_rstd,
+                                       float count, int training, float* __restrict__ dgain, float* __restrict__ dbias, int ldd,
+                                       float* __restrict__ dstat, int N, int C) {
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+        const float mean = mean_rstd[c], rstd = mean_rstd[C + c];
+        const int rows = (ld == 0) ? 1 : N;
+        float drstd = 0.f, dmean = 0.f;
+        for (int n = 0; n < rows; ++n) {
+            const float g = gain[(long)n * ld + c] + (plus_one ? 1.f : 0.f);
+            const float ds = dscale[(long)n * C + c], dt = dshift[(long)n * C + c];
+            const float e = ds - dt * mean;          // d/d(scale) with shift = bias - mean*scale folded in
+            dgain[(long)n * ldd + c] = e * rstd;
+            dbias[(long)n * ldd + c] = dt;
+            drstd += e * g;
+            dmean -= dt * rstd * g;
+        }
+        if (dstat) {
+            if (training) {
+                const float dvar = -0.5f * rstd * rstd * rstd * drstd;
+                dstat[C + c] = dvar / count;                          // d sumsq
+                dstat[c] = (dmean - 2.f * mean * dvar) / count;       // d sum
+            } else {
+                dstat[c] = 0.f;
+                dstat[C + c] = 0.f;
+            }
+        }
+    }
+}
+
+extern "C" int ieagan_bn_finalize_bwd(const float* dscale, const float* dshift, const float* gain, int ld, int plus_one,
+                                      const float* mean_rstd, float count, int training, float* dgain, float* dbias,
+                                      int ldd, float* dstat, int N, int C, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof("bn_finalize_bwd", 0.0, 0.0, st);
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, dscale, dshift, gain, ld, plus_one,
+                       mean_rstd, count, training, dgain, dbias, ldd, dstat, N, C);
+    CHECK_LAUNCH("bn_finalize_bwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// res_bwd: gradient of the conv epilogue's residual operand A (channels [0, Ca) of a tensor with
+// Cr channels): mode 1 -> residual lived at half resolution (sum the 2x2 block), mode 2 -> at double
+// resolution (0.25 * expand).  Channels [Ca, Cr) get zeros.  g: [N,H,W,Cg].  dr: [N,Hr,Wr,Cr].
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void res_bwd_kernel(const bf16* __restrict__ g, int Cg, bf16* __restrict__ dr, int Cr, int Ca,
+                                                      int N, int Hr, int Wr) {
+    const int groups = Cr >> 3;
+    const long chunks = (long)N * Hr * Wr * groups;
+    const int H = (MODE == 1) ? 2 * Hr : Hr / 2, W = (MODE == 1) ? 2 * Wr : Wr / 2;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < chunks; idx += (long)gridDim.x * 256) {
+        const int cg = (int)(idx % groups);
+        const long sp = idx / groups;
+        const int ws = (int)(sp % Wr);
+        const long t = sp / Wr;
+        const int hs = (int)(t % Hr), n = (int)(t / Hr);
+        bf16x8 o = zero8();
+        if (cg * 8 < Ca) {
+            if (MODE == 1) {
+                float d[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) d[i] = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bf16x8 v = *(const bf16x8*)(g + (((long)n * H + 2 * hs + (q >> 1)) * W + 2 * ws + (q & 1)) * Cg + cg * 8);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) d[i] += bf2f(v[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = f2bf(d[i]);
+            } else {
+                const bf16x8 v = *(const bf16x8*)(g + (((long)n * H + (hs >> 1)) * W + (ws >> 1)) * Cg + cg * 8);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = f2bf(0.25f * bf2f(v[i]));
+            }
+        }
+        *(bf16x8*)(dr + idx * 8) = o;
+    }
+}
+
+extern "C" int ieagan_res_bwd(const void* g, int Cg, void* dr, int Cr, int Ca, int mode, int N, int Hr, int Wr, void* stream) {
+    CHECK_ARG(mode == 1 || mode == 2, "res_bwd: mode must be 1 (upsampled residual) or 2 (pooled residual)");
+    CHECK_ARG(Cr % 8 == 0 && Ca % 8 == 0 && Ca <= Cr && Ca <= Cg, "res_bwd: bad channel counts");
+    CHECK_ARG(mode != 2 || (Hr % 2 == 0 && Wr % 2 == 0), "res_bwd: pooled residual needs even size");
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof("res_bwd", 0.0, 2.0 * N * Hr * Wr * (double)Cr * (mode == 1 ? 5.0 : 1.25), st);
+    long blocks = ((long)N * Hr * Wr * (Cr / 8) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    if (mode == 1) hipLaunchKernelGGL((res_bwd_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, st, (const bf16*)g, Cg, (bf16*)dr, Cr, Ca, N, Hr, Wr);
+    else hipLaunchKernelGGL((res_bwd_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, st, (const bf16*)g, Cg, (bf16*)dr, Cr, Ca, N, Hr, Wr);
+    CHECK_LAUNCH("res_bwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// module-boundary layout changes.  NCHW fp32 [N,C,HW] <-> NHWC bf16 [N,HW,C] through an LDS tile of
+// 32 pixels x 32 channels so that both sides stay coalesced.  Optional (sum, sumsq) statistics of the
+// bf16-rounded values for a BatchNorm that consumes the converted tensor.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, bf16* __restrict__ out,
+                                                           float* __restrict__ stats, int C, int HW) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, p = p0 + tx;
+        tile[j][tx] = (c < C && p < HW) ? in[((long)n * C + c) * HW + p] : 0.f;
+    }
+    __syncthreads();
+    float s1 = 0.f, s2 = 0.f;   // channel c0+tx over the pixels this thread writes
+    for (int j = ty; j < 32; j += 8) {
+        const int p = p0 + j, c = c0 + tx;
+        if (p < HW && c < C) {
+            const bf16 v = f2bf(tile[tx][j]);
+            out[((long)n * HW + p) * C + c] = v;
+            const float f = bf2f(v);
+            s1 += f;
+            s2 += f * f;
+        }
+    }
+    if (stats != nullptr && c0 + tx < C) {
+        float* st = stats + (long)((blockIdx.x + blockIdx.z) % STAT_REPL) * 2 * C;
+        atomicAdd(st + c0 + tx, s1);
+        atomicAdd(st + C + c0 + tx, s2);
+    }
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const bf16* __restrict__ in, float* __restrict__ out, int C, int HW) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int p = p0 + j, c = c0 + tx;
+        tile[j][tx] = (c < C && p < HW) ? bf2f(in[((long)n * HW + p) * C + c]) : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, p = p0 + tx;
+        if (c < C && p < HW) out[((long)n * C + c) * HW + p] = tile[tx][j];
+    }
+}
+
+extern "C" int ieagan_nchw_to_nhwc(const float* in, void* out, float* stats, int N, int C, int HW, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof("nchw_to_nhwc", 0.0, 6.0 * N * C * (double)HW, st);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(HW, 32), cdiv(C, 32), N), dim3(256), 0, st, in, (bf16*)out, stats, C, HW);
+    CHECK_LAUNCH("nchw_to_nhwc");
+    return 0;
+}
+
+extern "C" int ieagan_nhwc_to_nchw(const void* in, float* out, int N, int C, int HW, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof("nhwc_to_nchw", 0.0, 6.0 * N * C * (double)HW, st);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(cdiv(HW, 32), cdiv(C, 32), N), dim3(256), 0, st, (const bf16*)in, out, C, HW);
+    CHECK_LAUNCH("nhwc_to_nchw");
+    return 0;
+}
+
+// per-channel (sum, sumsq) of an NHWC bf16 tensor -> replicated stats (used when the producer was not
+// one of the conv kernels).
+__global__ __launch_bounds__(256) void stats_kernel(const bf16* __restrict__ x, float* __restrict__ stats, long P, int C) {
+    __shared__ float red[256 * 8];
+    const int groups = C >> 3;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
+    const long chunks = P * groups;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < chunks; idx += (long)gridDim.x * 256) {
+        const bf16x8 v = *(const bf16x8*)(x + idx * 8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float f = bf2f(v[i]);
+            s1[i] += f;
+            s2[i] += f * f;
+        }
+    }
+    float* st = stats + (long)(blockIdx.x % STAT_REPL) * 2 * C;
+    reduce_groups_atomic(s1, groups, st, red);
+    reduce_groups_atomic(s2, groups, st + C, red);
+}
+
+extern "C" int ieagan_channel_stats(const void* x, float* stats, long P, int C, void* stream) {
+    CHECK_ARG(C % 8 == 0 && 256 % (C / 8) == 0, "channel_stats: C=%d unsupported", C);
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof("channel_stats", 0.0, 2.0 * P * C, st);
+    long blocks = (P * (C / 8) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(stats_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16*)x, stats, P, C);
+    CHECK_LAUNCH("channel_stats");
+    return 0;
+}

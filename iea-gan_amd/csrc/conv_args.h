@@ -1,0 +1,11 @@
+// Kernel argument blocks of the conv launchers: the public C structs, passed by value to the kernels.
+#pragma once
+#include "common.h"
+#include "../../include/ieagan_hip.h"
+
+typedef ieagan_src_desc SrcDesc;
+typedef ieagan_conv_desc ConvArgs;
+typedef ieagan_wgrad_desc WgradArgs;
+
+int conv_gather_launch(const ConvArgs& a, hipStream_t st);
+int conv_wgrad_launch(const WgradArgs& a, hipStream_t st, int use_tr);

@@ -1,0 +1,427 @@
+// Implicit-GEMM convolutions on MFMA (gfx950), bf16 NHWC activations, fp32 accumulate.
+//
+//   conv_gather : out[M = N*H*W, Cout] = A[M, taps*Cin] * Wp^T,  A gathered on the fly with the
+//                 fused prologue (class-conditional BN apply, ReLU, nearest x2 upsample or 2x2 average
+//                 pool of the source) and the fused epilogue (bias, residual add with its own
+//                 resample / channel slice, ReLU-mask multiply, per-channel sum / sum-of-squares for
+//                 the next BatchNorm).  Used for forward and, with the transposed/flipped weight pack,
+//                 for dgrad.  Replaces F.conv2d + F.batch_norm + relu + F.interpolate + AvgPool2d +
+//                 the residual add of the reference blocks (model.py:54-71, 541-557; layers.py:197-206).
+//   conv_wgrad  : dWp[Cout, taps*Cin] += G^T * A over pixel tiles; both operands staged in LDS in
+//                 their natural NHWC layout and read K(pixel)-major with ds_read_b64_tr_b16.
+//
+// MFMA: v_mfma_f32_16x16x32_bf16.  Lane l: A[row l&15][k 8*(l>>4)+j], B[k 8*(l>>4)+j][col l&15],
+// D[row 4*(l>>4)+r][col l&15].
+#include "common.h"
+#include "conv_args.h"
+
+// ------------------------------------------------------------------------------------------------
+// A-operand gather with fused prologue.  Returns 8 consecutive channels [c, c+8) of the (virtual)
+// conv-input pixel (n, hh, ww) at conv resolution; zero outside the image (conv padding is applied
+// AFTER the activation, as in the reference where the activated tensor is what gets padded).
+// ------------------------------------------------------------------------------------------------
+template <bool AFF, bool RELU>
+__device__ __forceinline__ void xform8(float (&v)[8], const SrcDesc& s, int n, int c) {
+    if (AFF) {
+        const f32x8 sc = *(const f32x8*)(s.scale + (long)n * s.aff_nstride + c);
+        const f32x8 sh = *(const f32x8*)(s.shift + (long)n * s.aff_nstride + c);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = v[i] * sc[i] + sh[i];
+    }
+    if (RELU) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
+    }
+}
+
+template <bool AFF, bool RELU, int RS>
+__device__ __forceinline__ bf16x8 gather8(const SrcDesc& s, int H, int W, int n, int hh, int ww, int c, bool ok) {
+    ok = ok && (hh >= 0) && (hh < H) && (ww >= 0) && (ww < W);
+    if (!ok) return zero8();
+    if (RS == 2) {  // conv pixel = mean of the 2x2 source block (AvgPool2d(2) of the activated source)
+        float acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bf16x8 raw = *(const bf16x8*)((const bf16*)s.x + (((long)n * s.Hs + 2 * hh + (q >> 1)) * s.Ws + 2 * ww + (q & 1)) * s.Cx + c);
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = bf2f(raw[i]);
+            xform8<AFF, RELU>(v, s, n, c);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += v[i];
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = f2bf(0.25f * acc[i]);
+        return o;
+    }
+    const int sh_ = (RS == 1) ? (hh >> 1) : hh, sw_ = (RS == 1) ? (ww >> 1) : ww;
+    const bf16x8 raw = *(const bf16x8*)((const bf16*)s.x + (((long)n * s.Hs + sh_) * s.Ws + sw_) * s.Cx + c);
+    if (!AFF && !RELU) return raw;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = bf2f(raw[i]);
+    xform8<AFF, RELU>(v, s, n, c);
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = f2bf(v[i]);
+    return o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv_gather: block = 4 waves, each wave 2 m-tiles (32 pixels) x NT n-tiles (16*NT channels).
+// ------------------------------------------------------------------------------------------------
+template <int TAPS, bool AFF, bool RELU, int RS, int NT>
+__global__ __launch_bounds__(256) void conv_gather_kernel(ConvArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int H = a.H, W = a.W, HW = H * W;
+    const long M = (long)a.N * HW;
+    const long m_base = ((long)blockIdx.x * 4 + wave) * 32;
+    const int n_base = blockIdx.y * NT * 16;
+
+    int pn[2], ph[2], pw[2];
+    bool pv[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const long m = m_base + mt * 16 + lr;
+        pv[mt] = m < M;
+        const long mm = pv[mt] ? m : 0;
+        pn[mt] = (int)(mm / HW);
+        const int rem = (int)(mm - (long)pn[mt] * HW);
+        ph[mt] = rem / W;
+        pw[mt] = rem - ph[mt] * W;
+    }
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int ksteps = a.Kpad >> 5;
+    const bf16* wrow = (const bf16*)a.w + (long)(n_base + lr) * a.Kpad + lg * 8;
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const int k = ks * 32 + lg * 8;
+        int tap = 0, c = k;
+        if (TAPS == 9) {
+            tap = k / a.Cin;
+            c = k - tap * a.Cin;
+        }
+        const bool kval = (TAPS == 9) ? (tap < 9) : (k < a.Cin);
+        const int dy = (TAPS == 9) ? (tap / 3 - 1) : 0;
+        const int dx = (TAPS == 9) ? (tap - (tap / 3) * 3 - 1) : 0;
+        bf16x8 bfrag[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bfrag[nt] = *(const bf16x8*)(wrow + (long)nt * 16 * a.Kpad + ks * 32);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const bf16x8 af = gather8<AFF, RELU, RS>(a.src, H, W, pn[mt], ph[mt] + dy, pw[mt] + dx, c, pv[mt] && kval);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfrag[nt], acc[mt][nt], 0, 0, 0);
+        }
+    }
+
+    // ---------------- epilogue
+    float s1[NT], s2[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) s1[nt] = s2[nt] = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long m = m_base + mt * 16 + lg * 4 + r;
+            if (m >= M) continue;
+            int n = 0, h = 0, w = 0;
+            if (a.ra != nullptr && a.ra_rs != 0) {
+                n = (int)(m / HW);
+                const int rem = (int)(m - (long)n * HW);
+                h = rem / W;
+                w = rem - h * W;
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int co = n_base + nt * 16 + lr;
+                float v = acc[mt][nt][r];
+                if (a.bias) v += a.bias[co];
+                if (a.ra != nullptr && co < a.Ca) {
+                    if (a.ra_rs == 0) {
+                        v += bf2f(((const bf16*)a.ra)[m * a.Cra + co]);
+                    } else if (a.ra_rs == 1) {  // residual lives at half resolution (nearest x2 upsample)
+                        v += bf2f(((const bf16*)a.ra)[(((long)n * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1)) * a.Cra + co]);
+                    } else {                    // residual lives at double resolution (2x2 average pool)
+                        const bf16* p = (const bf16*)a.ra + (((long)n * (2 * H) + 2 * h) * (2 * W) + 2 * w) * a.Cra + co;
+                        const long rs_ = (long)2 * W * a.Cra;
+                        v += 0.25f * (bf2f(p[0]) + bf2f(p[a.Cra]) + bf2f(p[rs_]) + bf2f(p[rs_ + a.Cra]));
+                    }
+                } else if (a.rb != nullptr && co >= a.Ca) {
+                    v += bf2f(((const bf16*)a.rb)[m * a.Crb + (co - a.Ca)]);
+                }
+                if (a.mask != nullptr && !(bf2f(((const bf16*)a.mask)[m * a.Cout + co]) > 0.f)) v = 0.f;
+                ((bf16*)a.out)[m * a.Cout + co] = f2bf(v);
+                s1[nt] += v;
+                s2[nt] += v * v;
+            }
+        }
+    }
+    if (a.stats != nullptr) {
+        __shared__ float red[4][NT * 16][2];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float x1 = s1[nt], x2 = s2[nt];
+            x1 += __shfl_xor(x1, 16, 64);
+            x1 += __shfl_xor(x1, 32, 64);
+            x2 += __shfl_xor(x2, 16, 64);
+            x2 += __shfl_xor(x2, 32, 64);
+            if (lg == 0) {
+                red[wave][nt * 16 + lr][0] = x1;
+                red[wave][nt * 16 + lr][1] = x2;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < NT * 16) {
+            const int t = threadIdx.x;
+            const float x1 = red[0][t][0] + red[1][t][0] + red[2][t][0] + red[3][t][0];
+            const float x2 = red[0][t][1] + red[1][t][1] + red[2][t][1] + red[3][t][1];
+            float* st = a.stats + (long)(blockIdx.x % STAT_REPL) * 2 * a.Cout;
+            atomicAdd(st + n_base + t, x1);
+            atomicAdd(st + a.Cout + n_base + t, x2);
+        }
+    }
+}
+
+template <int TAPS, bool AFF, bool RELU, int RS>
+static int launch_gather_nt(const ConvArgs& a, hipStream_t st) {
+    const long M = (long)a.N * a.H * a.W;
+    const unsigned gx = (unsigned)((M + 127) / 128);
+    if (a.Cout % 64 == 0) {
+        hipLaunchKernelGGL((conv_gather_kernel<TAPS, AFF, RELU, RS, 4>), dim3(gx, a.Cout / 64), dim3(256), 0, st, a);
+    } else if (a.Cout % 32 == 0) {
+        hipLaunchKernelGGL((conv_gather_kernel<TAPS, AFF, RELU, RS, 2>), dim3(gx, a.Cout / 32), dim3(256), 0, st, a);
+    } else {
+        hipLaunchKernelGGL((conv_gather_kernel<TAPS, AFF, RELU, RS, 1>), dim3(gx, a.Cout / 16), dim3(256), 0, st, a);
+    }
+    return 0;
+}
+
+template <int TAPS, int RS>
+static int launch_gather_pro(const ConvArgs& a, hipStream_t st) {
+    const bool aff = a.src.scale != nullptr, relu = a.src.relu != 0;
+    if (aff && relu) return launch_gather_nt<TAPS, true, true, RS>(a, st);
+    if (aff) return launch_gather_nt<TAPS, true, false, RS>(a, st);
+    if (relu) return launch_gather_nt<TAPS, false, true, RS>(a, st);
+    return launch_gather_nt<TAPS, false, false, RS>(a, st);
+}
+
+int conv_gather_launch(const ConvArgs& a, hipStream_t st) {
+    CHECK_ARG(a.taps == 1 || a.taps == 9, "conv: taps must be 1 or 9 (got %d)", a.taps);
+    CHECK_ARG(a.Cin % 16 == 0 && a.Cout % 16 == 0, "conv: Cin/Cout must be multiples of 16 (%d,%d)", a.Cin, a.Cout);
+    CHECK_ARG(a.Kpad % 32 == 0 && a.Kpad >= a.taps * a.Cin, "conv: bad Kpad %d", a.Kpad);
+    CHECK_ARG(a.src.rs >= 0 && a.src.rs <= 2, "conv: bad resample mode %d", a.src.rs);
+    CHECK_ARG(a.src.Cx % 8 == 0, "conv: source channel stride must be a multiple of 8");
+    CHECK_ARG((a.src.scale == nullptr) == (a.src.shift == nullptr), "conv: scale/shift must come together");
+    if (a.src.rs == 1) CHECK_ARG(a.H == 2 * a.src.Hs && a.W == 2 * a.src.Ws, "conv: upsample geometry mismatch");
+    if (a.src.rs == 2) CHECK_ARG(2 * a.H == a.src.Hs && 2 * a.W == a.src.Ws, "conv: pool geometry mismatch");
+    if (a.src.rs == 0) CHECK_ARG(a.H == a.src.Hs && a.W == a.src.Ws, "conv: geometry mismatch");
+    if (a.ra) CHECK_ARG(a.Ca <= a.Cout && a.Ca <= a.Cra, "conv: residual channel slice out of range");
+    if (a.ra && a.ra_rs == 1) CHECK_ARG(a.H % 2 == 0 && a.W % 2 == 0, "conv: upsampled residual needs even H, W");
+    const double flops = 2.0 * a.N * a.H * a.W * (double)a.Cout * a.taps * a.Cin;
+    const double bytes = 2.0 * a.N * ((double)a.src.Hs * a.src.Ws * a.Cin + (double)a.H * a.W * a.Cout);
+    ProfScope prof(a.taps == 9 ? "conv3x3_gather" : "conv1x1_gather", flops, bytes, st);
+    int rc;
+    if (a.taps == 9) {
+        if (a.src.rs == 0) rc = launch_gather_pro<9, 0>(a, st);
+        else if (a.src.rs == 1) rc = launch_gather_pro<9, 1>(a, st);
+        else { ieagan_set_error("conv: 3x3 with pooled source is not instantiated"); return IEAGAN_EINVAL; }
+    } else {
+        if (a.src.rs == 0) rc = launch_gather_pro<1, 0>(a, st);
+        else if (a.src.rs == 2) rc = launch_gather_pro<1, 2>(a, st);
+        else { ieagan_set_error("conv: 1x1 with upsampled source is not instantiated"); return IEAGAN_EINVAL; }
+    }
+    CHECK_LAUNCH("conv_gather");
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv_wgrad
+// ------------------------------------------------------------------------------------------------
+#define WG_TH 8
+#define WG_TW 16
+
+// 8 K(pixel)-consecutive values of one column, from a [rows][cols] 16-bit LDS image.
+// TR: two ds_read_b64_tr_b16 (lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3 and
+// receives column (lane&15) of the 4 rows).  !TR: eight scalar reads (reference path for the test).
+template <bool TR>
+__device__ __forceinline__ bf16x8 frag_T(const bf16* lds, int row0_bytes_unused, int stride_elems, int pix0, int col0, int lr) {
+    bf16x8 f;
+    if (TR) {
+        const int q = lr >> 2, p = lr & 3;
+        const bf16* p0 = lds + (pix0 + q) * stride_elems + col0 + 4 * p;
+        const bf16* p1 = p0 + 4 * stride_elems;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)p0);
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)p1);
+        f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+        f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = lds[(pix0 + j) * stride_elems + col0 + lr];
+    }
+    return f;
+}
+
+template <int TAPS, bool AFF, bool RELU, int RS, int MT, bool TR>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int HALO = (TAPS == 9) ? 1 : 0;
+    constexpr int AW = WG_TW + 2 * HALO, AH = WG_TH + 2 * HALO;
+    const int GC = MT * 16;                       // cout columns of the g tile
+    bf16* lds_g = (bf16*)smem;                    // [WG_TH*WG_TW][GC]
+    bf16* lds_a = lds_g + WG_TH * WG_TW * GC;     // [AH*AW][Cin]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int H = a.H, W = a.W, Cin = a.Cin;
+    const int tiles_w = (W + WG_TW - 1) / WG_TW, tiles_h = (H + WG_TH - 1) / WG_TH;
+    const int tiles_img = tiles_w * tiles_h;
+    const long tiles_total = (long)a.N * tiles_img;
+    const int cout0 = blockIdx.z * GC;
+    const int cin_tiles = Cin >> 4;
+    const int nt_total = TAPS * cin_tiles;
+
+    // this wave's 4 n-tiles: (tap, cin0); invalid ones are clamped for addressing and skipped at the end
+    int t_dy[4], t_dx[4], t_c0[4], t_kcol[4];
+    bool t_ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ntg = blockIdx.y * 16 + wave * 4 + j;
+        t_ok[j] = ntg < nt_total;
+        const int q = t_ok[j] ? ntg : 0;
+        const int tap = q / cin_tiles;
+        t_c0[j] = (q - tap * cin_tiles) * 16;
+        t_dy[j] = (TAPS == 9) ? tap / 3 : 0;          // already offset by +HALO-1 (dy-1+1)
+        t_dx[j] = (TAPS == 9) ? tap - (tap / 3) * 3 : 0;
+        t_kcol[j] = tap * Cin + t_c0[j];
+    }
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const long tile_begin = (long)blockIdx.x * a.tiles_per_block;
+    long tile_end = tile_begin + a.tiles_per_block;
+    if (tile_end > tiles_total) tile_end = tiles_total;
+    for (long tile = tile_begin; tile < tile_end; ++tile) {
+        const int n = (int)(tile / tiles_img);
+        const int tr_ = (int)(tile - (long)n * tiles_img);
+        const int h0 = (tr_ / tiles_w) * WG_TH, w0 = (tr_ % tiles_w) * WG_TW;
+        __syncthreads();   // previous tile's fragments consumed
+        // ---- stage g tile: 128 pixels x GC couts, 16-byte chunks
+        for (int idx = threadIdx.x; idx < WG_TH * WG_TW * (GC / 8); idx += 256) {
+            const int px = idx / (GC / 8), cc = idx - px * (GC / 8);
+            const int hh = h0 + px / WG_TW, ww = w0 + px % WG_TW;
+            bf16x8 v = zero8();
+            if (hh < H && ww < W) v = *(const bf16x8*)((const bf16*)a.g + (((long)n * H + hh) * W + ww) * a.Cg + cout0 + cc * 8);
+            *(bf16x8*)(lds_g + px * GC + cc * 8) = v;
+        }
+        // ---- stage a tile (+halo) with the fused prologue
+        for (int idx = threadIdx.x; idx < AH * AW * (Cin / 8); idx += 256) {
+            const int hp = idx / (Cin / 8), cc = idx - hp * (Cin / 8);
+            const int hh = h0 - HALO + hp / AW, ww = w0 - HALO + hp % AW;
+            const bf16x8 v = gather8<AFF, RELU, RS>(a.src, H, W, n, hh, ww, cc * 8, true);
+            *(bf16x8*)(lds_a + hp * Cin + cc * 8) = v;
+        }
+        __syncthreads();
+        // ---- 4 k-steps of 32 pixels (two tile rows each); lane group lg owns 8 consecutive pixels
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int row = 2 * ks + (lg >> 1), col = (lg & 1) * 8;
+            bf16x8 af[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) af[mt] = frag_T<TR>(lds_g, 0, GC, row * WG_TW + col, mt * 16, lr);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bf16x8 bfr = frag_T<TR>(lds_a, 0, Cin, (row + t_dy[j]) * AW + col + t_dx[j], t_c0[j], lr);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfr, acc[mt][j], 0, 0, 0);
+            }
+        }
+    }
+    // ---- accumulate into dWp[cout][k]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (!t_ok[j]) continue;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                atomicAdd(a.dw + (long)(cout0 + mt * 16 + lg * 4 + r) * a.Kpad + t_kcol[j] + lr, acc[mt][j][r]);
+    }
+}
+
+template <int TAPS, bool AFF, bool RELU, int RS, bool TR>
+static void launch_wgrad_mt(const WgradArgs& a, hipStream_t st, int mt, dim3 grid, size_t lds) {
+    switch (mt) {
+        case 1: hipLaunchKernelGGL((conv_wgrad_kernel<TAPS, AFF, RELU, RS, 1, TR>), grid, dim3(256), lds, st, a); break;
+        case 2: hipLaunchKernelGGL((conv_wgrad_kernel<TAPS, AFF, RELU, RS, 2, TR>), grid, dim3(256), lds, st, a); break;
+        case 4: hipLaunchKernelGGL((conv_wgrad_kernel<TAPS, AFF, RELU, RS, 4, TR>), grid, dim3(256), lds, st, a); break;
+        default: hipLaunchKernelGGL((conv_wgrad_kernel<TAPS, AFF, RELU, RS, 8, TR>), grid, dim3(256), lds, st, a); break;
+    }
+}
+
+template <int TAPS, int RS, bool TR>
+static void launch_wgrad_pro(const WgradArgs& a, hipStream_t st, int mt, dim3 grid, size_t lds) {
+    const bool aff = a.src.scale != nullptr, relu = a.src.relu != 0;
+    if (aff && relu) launch_wgrad_mt<TAPS, true, true, RS, TR>(a, st, mt, grid, lds);
+    else if (aff) launch_wgrad_mt<TAPS, true, false, RS, TR>(a, st, mt, grid, lds);
+    else if (relu) launch_wgrad_mt<TAPS, false, true, RS, TR>(a, st, mt, grid, lds);
+    else launch_wgrad_mt<TAPS, false, false, RS, TR>(a, st, mt, grid, lds);
+}
+
+int conv_wgrad_launch(const WgradArgs& a0, hipStream_t st, int use_tr) {
+    WgradArgs a = a0;
+    CHECK_ARG(a.taps == 1 || a.taps == 9, "wgrad: taps must be 1 or 9");
+    CHECK_ARG(a.Cin % 16 == 0 && a.Cout % 16 == 0, "wgrad: Cin/Cout must be multiples of 16 (%d,%d)", a.Cin, a.Cout);
+    CHECK_ARG(a.Kpad >= a.taps * a.Cin, "wgrad: bad Kpad");
+    CHECK_ARG(a.Cg >= a.Cout && a.Cg % 8 == 0, "wgrad: bad g channel stride %d", a.Cg);
+    if (a.src.rs == 1) CHECK_ARG(a.H == 2 * a.src.Hs && a.W == 2 * a.src.Ws, "wgrad: upsample geometry mismatch");
+    if (a.src.rs == 2) CHECK_ARG(2 * a.H == a.src.Hs && 2 * a.W == a.src.Ws, "wgrad: pool geometry mismatch");
+    if (a.src.rs == 0) CHECK_ARG(a.H == a.src.Hs && a.W == a.src.Ws, "wgrad: geometry mismatch");
+    // cout chunking: MT m-tiles per block (<= 8)
+    int mt = 8;
+    if (a.Cout % 128 != 0) mt = (a.Cout % 64 == 0) ? 4 : (a.Cout % 32 == 0) ? 2 : 1;
+    const int gz = a.Cout / (mt * 16);
+    const int nt_total = a.taps * (a.Cin / 16);
+    const int gy = (nt_total + 15) / 16;
+    const long tiles = (long)a.N * ((a.H + WG_TH - 1) / WG_TH) * ((a.W + WG_TW - 1) / WG_TW);
+    // split-K over ~1024 blocks in x (each block atomically adds its partial sums once)
+    long target = 1024 / (gy * gz);
+    if (target < 64) target = 64;
+    int tpb = (int)((tiles + target - 1) / target);
+    if (tpb < 1) tpb = 1;
+    a.tiles_per_block = tpb;
+    const int gx = (int)((tiles + tpb - 1) / tpb);
+    const int halo = (a.taps == 9) ? 1 : 0;
+    const size_t lds = (size_t)WG_TH * WG_TW * mt * 16 * 2 + (size_t)(WG_TH + 2 * halo) * (WG_TW + 2 * halo) * a.Cin * 2;
+    CHECK_ARG(lds <= 160 * 1024, "wgrad: LDS request %zu too large", lds);
+    const double flops = 2.0 * a.N * a.H * a.W * (double)a.Cout * a.taps * a.Cin;
+    const double bytes = 2.0 * a.N * ((double)a.src.Hs * a.src.Ws * a.Cin + (double)a.H * a.W * a.Cout);
+    ProfScope prof(a.taps == 9 ? "conv3x3_wgrad" : "conv1x1_wgrad", flops, bytes, st);
+    dim3 grid(gx, gy, gz);
+#define WG_DISPATCH(TR)                                                                  \
+    if (a.taps == 9) {                                                                   \
+        if (a.src.rs == 0) launch_wgrad_pro<9, 0, TR>(a, st, mt, grid, lds);             \
+        else if (a.src.rs == 1) launch_wgrad_pro<9, 1, TR>(a, st, mt, grid, lds);        \
+        else { ieagan_set_error("wgrad: 3x3 with pooled source not instantiated"); return IEAGAN_EINVAL; } \
+    } else {                                                                             \
+        if (a.src.rs == 0) launch_wgrad_pro<1, 0, TR>(a, st, mt, grid, lds);             \
+        else if (a.src.rs == 2) launch_wgrad_pro<1, 2, TR>(a, st, mt, grid, lds);        \
+        else { ieagan_set_error("wgrad: 1x1 with upsampled source not instantiated"); return IEAGAN_EINVAL; } \
+    }
+    if (use_tr) { WG_DISPATCH(true) } else { WG_DISPATCH(false) }
+#undef WG_DISPATCH
+    CHECK_LAUNCH("conv_wgrad");
+    return 0;
+}

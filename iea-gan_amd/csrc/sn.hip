@@ -1,0 +1,214 @@
+// Batched spectral normalisation (one power iteration, one singular value) for ALL spectrally
+// normalised layers of a network in three launches, instead of ~5 tiny ATen ops per layer
+// (the reference issues 147 (G) + 64 (D) power iterations per forward: layers.py:89-111, 151-165):
+//   phase 1: v_raw = u W                       (atomic column sums per row chunk)
+//   phase 2: t = W v,  v = v_raw / max(|v_raw|, eps);  tt += t^2
+//   phase 3: sigma = tt / max(sqrt(tt), eps), u' = t / max(sqrt(tt), eps);  u <- u' and sv <- sigma when
+//            training;  write the normalised weight W / sigma in the layout its consumer wants
+// and the backward through sigma (sigma = u' W v^T with u', v constant):
+//   dW = dWsn / sigma - (<dWsn, W> / sigma^2) u'^T v.
+//
+// Layer table: int64 [L][SN_FIELDS], offsets in elements relative to the base pointers.
+#include "common.h"
+
+#define SN_FIELDS 16
+enum { F_W = 0, F_U, F_SV, F_OUT, F_IN, F_TAPS, F_CIN, F_KIND, F_CTX, F_PACK, F_PACK2, F_KPAD, F_KPAD2 };
+// kinds: 0 fp32 [out][in] copy (linear / embedding)
+//        1 conv pack: bf16 fwd [out][kpad] (k = tap*cin + c) at F_PACK and bf16 dgrad [cin][kpad2]
+//          (k' = (taps-1-tap)*out + o) at F_PACK2 (byte offsets)
+//        2 single-channel INPUT conv (weight [C][1][3][3]) -> fp32 [9][C] at F_PACK
+//        3 single-channel OUTPUT conv (weight [1][C][3][3]) -> fp32 [9][C] at F_PACK
+// ctx layout per layer (fp32, at F_CTX): [0] sigma, [1] tt, [2] |v_raw|^2 (unused), [8 .. 8+out) u',
+//   [8+out .. 8+out+in) v_raw, [8+out+in .. 8+out+2*in) v
+#define SN_ROWS 32
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
+    return s;
+}
+
+__global__ __launch_bounds__(256) void sn_phase1_kernel(const long* __restrict__ tab, const int* __restrict__ blocks,
+                                                        const float* __restrict__ params, float* __restrict__ ctx) {
+    const long* L = tab + (long)blocks[2 * blockIdx.x] * SN_FIELDS;
+    const int row0 = blocks[2 * blockIdx.x + 1];
+    const int out = (int)L[F_OUT], in = (int)L[F_IN];
+    const float* W = params + L[F_W];
+    const float* u = params + L[F_U];
+    float* vraw = ctx + L[F_CTX] + 8 + out;
+    const int r1 = min(row0 + SN_ROWS, out);
+    for (int i = threadIdx.x; i < in; i += 256) {
+        float s = 0.f;
+        for (int o = row0; o < r1; ++o) s += u[o] * W[(long)o * in + i];
+        atomicAdd(vraw + i, s);
+    }
+}
+
+__global__ __launch_bounds__(256) void sn_phase2_kernel(const long* __restrict__ tab, const int* __restrict__ blocks,
+                                                        const float* __restrict__ params, float* __restrict__ ctx, float eps) {
+    __shared__ float red[4];
+    const long* L = tab + (long)blocks[2 * blockIdx.x] * SN_FIELDS;
+    const int row0 = blocks[2 * blockIdx.x + 1];
+    const int out = (int)L[F_OUT], in = (int)L[F_IN];
+    const float* W = params + L[F_W];
+    float* c = ctx + L[F_CTX];
+    const float* vraw = c + 8 + out;
+    float* v = c + 8 + out + in;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < in; i += 256) ss += vraw[i] * vraw[i];
+    ss = block_sum(ss, red);
+    const float inv = 1.f / fmaxf(sqrtf(ss), eps);
+    if (row0 == 0)
+        for (int i = threadIdx.x; i < in; i += 256) v[i] = vraw[i] * inv;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r1 = min(row0 + SN_ROWS, out);
+    float tt = 0.f;
+    for (int o = row0 + wave; o < r1; o += 4) {
+        float s = 0.f;
+        for (int i = lane; i < in; i += 64) s += W[(long)o * in + i] * (vraw[i] * inv);
+        s = wave_sum(s);
+        if (lane == 0) {
+            c[8 + o] = s;
+            tt += s * s;
+        }
+    }
+    if (lane == 0 && tt != 0.f) atomicAdd(c + 1, tt);
+}
+
+__global__ __launch_bounds__(256) void sn_phase3_kernel(const long* __restrict__ tab, const int* __restrict__ blocks,
+                                                        float* __restrict__ params, float* __restrict__ ctx, char* __restrict__ pack,
+                                                        float eps, int training) {
+    const long* L = tab + (long)blocks[2 * blockIdx.x] * SN_FIELDS;
+    const int row0 = blocks[2 * blockIdx.x + 1];
+    const int out = (int)L[F_OUT], in = (int)L[F_IN], taps = (int)L[F_TAPS], cin = (int)L[F_CIN], kind = (int)L[F_KIND];
+    const int kpad = (int)L[F_KPAD], kpad2 = (int)L[F_KPAD2];
+    const float* W = params + L[F_W];
+    float* c = ctx + L[F_CTX];
+    const float tt = c[1];
+    const float un = fmaxf(sqrtf(tt), eps);
+    const float sigma = tt / un;
+    const float isg = 1.f / sigma;
+    const int r1 = min(row0 + SN_ROWS, out);
+    // every block of the layer rescales its own rows of t into u'; no block reads another's rows
+    __syncthreads();
+    for (int o = row0 + threadIdx.x; o < r1; o += 256) {
+        const float un_o = c[8 + o] / un;
+        c[8 + o] = un_o;
+        if (training) params[L[F_U] + o] = un_o;
+    }
+    if (row0 == 0 && threadIdx.x == 0) {
+        c[0] = sigma;
+        if (training) params[L[F_SV]] = sigma;
+    }
+    const int rows = r1 - row0;
+    if (kind == 0) {
+        float* dst = (float*)(pack + L[F_PACK]);
+        for (long e = threadIdx.x; e < (long)rows * in; e += 256) dst[(long)row0 * in + e] = W[(long)row0 * in + e] * isg;
+    } else if (kind == 1) {
+        bf16* p1 = (bf16*)(pack + L[F_PACK]);
+        bf16* p2 = (bf16*)(pack + L[F_PACK2]);
+        for (long e = threadIdx.x; e < (long)rows * kpad; e += 256) {       // forward pack (incl. zero padding)
+            const int o = row0 + (int)(e / kpad), k = (int)(e % kpad);
+            float v = 0.f;
+            if (k < taps * cin) {
+                const int tap = k / cin, ci = k - tap * cin;
+                v = W[(long)o * in + ci * taps + tap] * isg;
+            }
+            p1[(long)o * kpad + k] = f2bf(v);
+        }
+        for (long e = threadIdx.x; e < (long)rows * in; e += 256) {         // dgrad pack
+            const int o = row0 + (int)(e / in), i = (int)(e % in);
+            const int ci = i / taps, tap = i - ci * taps;
+            p2[(long)ci * kpad2 + (taps - 1 - tap) * out + o] = f2bf(W[(long)o * in + i] * isg);
+        }
+        // zero padding columns of the dgrad pack: k' in [taps*out, kpad2), written by the block that owns row 0
+        if (row0 == 0 && kpad2 > taps * out) {
+            const int padw = kpad2 - taps * out;
+            for (long e = threadIdx.x; e < (long)cin * padw; e += 256)
+                p2[(e / padw) * kpad2 + taps * out + (e % padw)] = f2bf(0.f);
+        }
+    } else {  // 2: weight [C][1][9] -> [9][C];   3: weight [1][C][9] -> [9][C]
+        float* dst = (float*)(pack + L[F_PACK]);
+        for (long e = threadIdx.x; e < (long)rows * in; e += 256) {
+            const int o = row0 + (int)(e / in), i = (int)(e % in);
+            if (kind == 2) dst[i * out + o] = W[(long)o * in + i] * isg;                 // i = tap, o = channel
+            else dst[(i % 9) * cin + (i / 9)] = W[(long)o * in + i] * isg;              // i = c*9 + tap
+        }
+    }
+}
+
+extern "C" int ieagan_sn_forward(const long* tab, const int* blocks, int nblocks, float* params, float* ctx, void* pack,
+                                 float eps, int training, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (nblocks <= 0) return 0;
+    ProfScope prof("sn_forward", 0.0, 0.0, st);
+    hipLaunchKernelGGL(sn_phase1_kernel, dim3(nblocks), dim3(256), 0, st, tab, blocks, (const float*)params, ctx);
+    hipLaunchKernelGGL(sn_phase2_kernel, dim3(nblocks), dim3(256), 0, st, tab, blocks, (const float*)params, ctx, eps);
+    hipLaunchKernelGGL(sn_phase3_kernel, dim3(nblocks), dim3(256), 0, st, tab, blocks, params, ctx, (char*)pack, eps, training);
+    CHECK_LAUNCH("sn_forward");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward through W / sigma for one layer.
+//   gsn : gradient w.r.t. the normalised weight in the consumer's layout
+//         kind 0: fp32 [out][in];  kind 1: fp32 [out][kpad] (k = tap*cin + c);  kind 2/3: fp32 [9][C]
+//   dW  : fp32, the parameter's own layout ([out][in] row-major == OIHW)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gsn_at(const float* gsn, int kind, int o, int i, int out, int in, int taps, int cin, int kpad) {
+    if (kind == 0) return gsn[(long)o * in + i];
+    if (kind == 1) {
+        const int ci = i / taps, tap = i - ci * taps;
+        return gsn[(long)o * kpad + tap * cin + ci];
+    }
+    if (kind == 2) return gsn[i * out + o];
+    return gsn[(i % 9) * cin + (i / 9)];
+}
+
+__global__ __launch_bounds__(256) void sn_bwd_inner_kernel(const float* __restrict__ gsn, const float* __restrict__ W, int kind,
+                                                           int out, int in, int taps, int cin, int kpad, float* __restrict__ inner) {
+    __shared__ float red[4];
+    const long total = (long)out * in;
+    float s = 0.f;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int o = (int)(e / in), i = (int)(e % in);
+        s += gsn_at(gsn, kind, o, i, out, in, taps, cin, kpad) * W[e];
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) atomicAdd(inner, s);
+}
+
+__global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const float* __restrict__ gsn, int kind, int out, int in, int taps, int cin,
+                                                           int kpad, const float* __restrict__ ctx, const float* __restrict__ inner,
+                                                           float* __restrict__ dW) {
+    const float sigma = ctx[0];
+    const float isg = 1.f / sigma;
+    const float coef = inner[0] * isg * isg;
+    const float* u = ctx + 8;
+    const float* v = ctx + 8 + out + in;
+    const long total = (long)out * in;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int o = (int)(e / in), i = (int)(e % in);
+        dW[e] = gsn_at(gsn, kind, o, i, out, in, taps, cin, kpad) * isg - coef * u[o] * v[i];
+    }
+}
+
+extern "C" int ieagan_sn_backward(const float* gsn, const float* W, int kind, int out, int in, int taps, int cin, int kpad,
+                                  const float* ctx, float* inner_scratch, float* dW, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    CHECK_ARG(kind >= 0 && kind <= 3, "sn_backward: bad kind");
+    ProfScope prof("sn_backward", 0.0, 0.0, st);
+    hipError_t e = hipMemsetAsync(inner_scratch, 0, sizeof(float), st);
+    if (e != hipSuccess) { ieagan_set_error("sn_backward: memset failed"); return IEAGAN_ELAUNCH; }
+    long blocks = ((long)out * in + 255) / 256;
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(sn_bwd_inner_kernel, dim3((unsigned)blocks), dim3(256), 0, st, gsn, W, kind, out, in, taps, cin, kpad, inner_scratch);
+    hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, gsn, kind, out, in, taps, cin, kpad, ctx, (const float*)inner_scratch, dW);
+    CHECK_LAUNCH("sn_backward");
+    return 0;
+}

@@ -1,0 +1,551 @@
+"""Autograd operators of the MI355X path: thin ``torch.autograd.Function`` shells around the C ABI.
+
+Internal activation format: bf16, NHWC, contiguous.  Statistics buffers: fp32 ``[STAT_REPL, 2, C]``
+(replicated per-channel sum / sum of squares).  PyTorch only provides device memory, streams and
+the autograd tape here; all arithmetic on activations happens in libieagan_hip.so.
+
+Fused operator ``conv`` = [BN apply (per-(n,c) scale/shift) + ReLU + nearest-x2 upsample | 2x2 avg
+pool] -> 1x1/3x3 convolution with the spectrally normalised weight -> [+bias, + residual (own
+resample / channel slice / concat), + batch statistics of the output].  Its backward folds the
+batch-statistics path of the *following* BatchNorm into the out-grad (g_eff = dout + dsum + 2 out
+dsumsq), so one BN layer costs one extra read in forward and no standalone pass over the tensor.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+import _hip as H
+from _hip import STAT_REPL
+
+BF16 = torch.bfloat16
+
+
+def _kpad(k: int) -> int:
+    return (k + 31) // 32 * 32
+
+
+def new_stats(C: int, device) -> torch.Tensor:
+    return torch.zeros(STAT_REPL, 2, C, dtype=torch.float32, device=device)
+
+
+# =====================================================================================================
+# Spectral-norm bank: every SN layer of a network in three launches per forward
+# =====================================================================================================
+KIND_PLAIN, KIND_CONV, KIND_C1_IN, KIND_C1_OUT = 0, 1, 2, 3
+
+
+class SNRecord:
+    """What one forward pass knows about one spectrally normalised layer."""
+    __slots__ = ("kind", "out", "inn", "taps", "cin", "kpad", "kpad2", "w_fwd", "w_bwd", "w_plain", "ctx")
+
+
+class SNBank:
+    """Layer table over a flat fp32 arena (parameters + buffers of one network).
+
+    ``entries``: list of (name, kind, weight, u0, sv0) where the tensors are views into ``arena``.
+    ``stack`` : names of kind-0 layers whose normalised weights must be laid out contiguously, in
+    this order, as one [sum(out), in] matrix (the 96 ccbn gain/bias linears of G)."""
+
+    ROWS = 32
+
+    def __init__(self, arena: torch.Tensor, entries, stack=()):
+        self.arena = arena
+        self.names = [e[0] for e in entries]
+        self.index = {n: i for i, n in enumerate(self.names)}
+        dev = arena.device
+        rows, blocks = [], []
+        ctx_off, pack_off = 0, 0
+        self.meta = []
+        base = arena.data_ptr()
+
+        def off(t):
+            d = t.data_ptr() - base
+            assert d % 4 == 0 and 0 <= d < arena.numel() * 4, "SN tensors must live in the arena"
+            return d // 4
+
+        order = list(stack) + [n for n in self.names if n not in set(stack)]
+        self.stack_rows = {}
+        srow = 0
+        place = {}
+        for n in order:      # pack offsets follow `order`; table rows follow `entries`
+            i = self.index[n]
+            _, kind, w, u, sv = entries[i]
+            out = w.shape[0]
+            inn = w.numel() // out
+            taps = 9 if (w.dim() == 4 and w.shape[-1] == 3) else 1
+            cin = w.shape[1] if w.dim() == 4 else inn
+            kpad = kpad2 = 0
+            p2 = 0
+            if kind == KIND_CONV:
+                kpad, kpad2 = _kpad(taps * cin), _kpad(taps * out)
+                p1 = pack_off
+                p2 = p1 + out * kpad * 2
+                nbytes = out * kpad * 2 + cin * kpad2 * 2
+            else:
+                p1 = pack_off
+                nbytes = out * inn * 4
+            place[n] = (p1, p2, kpad, kpad2, taps, cin, out, inn)
+            pack_off += (nbytes + 255) // 256 * 256
+            if n in stack:
+                self.stack_rows[n] = (srow, out)
+                srow += out
+        self.stack_total = srow
+        for i, (n, kind, w, u, sv) in enumerate(entries):
+            p1, p2, kpad, kpad2, taps, cin, out, inn = place[n]
+            row = [0] * H.SN_FIELDS
+            row[0:13] = [off(w), off(u), off(sv), out, inn, taps, cin, kind, ctx_off, p1, p2, kpad, kpad2]
+            rows.append(row)
+            self.meta.append((kind, out, inn, taps, cin, kpad, kpad2, ctx_off, p1, p2))
+            ctx_off += (8 + out + 2 * inn + 7) // 8 * 8
+            for r0 in range(0, out, self.ROWS):
+                blocks.append([i, r0])
+        self.ctx_size, self.pack_size = ctx_off, pack_off
+        self.table = torch.tensor(rows, dtype=torch.int64, device=dev)
+        self.blocks = torch.tensor(blocks, dtype=torch.int32, device=dev)
+        self.nblocks = len(blocks)
+
+    def run(self, training: bool, eps: float):
+        dev = self.arena.device
+        ctx = torch.zeros(self.ctx_size, dtype=torch.float32, device=dev)
+        pack = torch.empty(self.pack_size, dtype=torch.uint8, device=dev)
+        H.call("ieagan_sn_forward", self.table.data_ptr(), self.blocks.data_ptr(), self.nblocks,
+               self.arena.data_ptr(), ctx.data_ptr(), pack.data_ptr(), float(eps), int(training), H.stream())
+        recs = {}
+        for n, (kind, out, inn, taps, cin, kpad, kpad2, coff, p1, p2) in zip(self.names, self.meta):
+            r = SNRecord()
+            r.kind, r.out, r.inn, r.taps, r.cin, r.kpad, r.kpad2 = kind, out, inn, taps, cin, kpad, kpad2
+            r.ctx = ctx[coff:coff + 8 + out + 2 * inn]
+            r.w_fwd = r.w_bwd = r.w_plain = None
+            if kind == KIND_CONV:
+                r.w_fwd = pack[p1:p1 + out * kpad * 2].view(BF16).view(out, kpad)
+                r.w_bwd = pack[p2:p2 + cin * kpad2 * 2].view(BF16).view(cin, kpad2)
+            elif kind == KIND_PLAIN:
+                r.w_plain = pack[p1:p1 + out * inn * 4].view(torch.float32).view(out, inn)
+            else:
+                r.w_plain = pack[p1:p1 + out * inn * 4].view(torch.float32)      # [9][C]
+            recs[n] = r
+        if self.stack_total:
+            first = self.meta[self.index[next(iter(self.stack_rows))]]
+            inn = first[2]
+            recs["__stack__"] = pack[first[8]:first[8] + self.stack_total * inn * 4].view(torch.float32).view(self.stack_total, inn)
+        return recs
+
+
+def sn_backward(gsn: torch.Tensor, weight: torch.Tensor, rec: SNRecord) -> torch.Tensor:
+    """dW (parameter layout) from the gradient w.r.t. the normalised weight (consumer layout)."""
+    dW = torch.empty_like(weight)
+    scratch = torch.empty(1, dtype=torch.float32, device=weight.device)
+    H.call("ieagan_sn_backward", gsn.data_ptr(), weight.data_ptr(), rec.kind, rec.out, rec.inn, rec.taps, rec.cin,
+           rec.kpad, rec.ctx.data_ptr(), scratch.data_ptr(), dW.data_ptr(), H.stream())
+    return dW
+
+
+class SNWeightFn(torch.autograd.Function):
+    """W -> W / sigma for a linear / embedding layer whose consumer is a plain library GEMM."""
+
+    @staticmethod
+    def forward(ctx, weight, rec):
+        ctx.rec = rec
+        ctx.save_for_backward(weight)
+        return rec.w_plain.view(weight.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        (weight,) = ctx.saved_tensors
+        return sn_backward(g.contiguous().float(), weight, ctx.rec), None
+
+
+class StackedSNLinearFn(torch.autograd.Function):
+    """All ccbn gain/bias SNLinear layers of G as ONE GEMM: [N, cond] x [cond, sum C]."""
+
+    @staticmethod
+    def forward(ctx, y, wstack, recs, names, *weights):
+        ctx.recs, ctx.names = recs, names
+        ctx.save_for_backward(y, wstack, *weights)
+        return y @ wstack.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        y, wstack, *weights = ctx.saved_tensors
+        dy = g @ wstack
+        gst = g.t() @ y                                   # [sum C, cond] gradient w.r.t. normalised rows
+        grads, r0 = [], 0
+        for n, w in zip(ctx.names, weights):
+            rec = ctx.recs[n]
+            grads.append(sn_backward(gst[r0:r0 + rec.out], w, rec))
+            r0 += rec.out
+        return (dy, None, None, None, *grads)
+
+
+# =====================================================================================================
+# BatchNorm finalize: statistics -> per-(n,c) scale / shift
+# =====================================================================================================
+class GainBank:
+    """The [N, sum C] matrix of all ccbn gains/biases of one generator forward, plus the shared
+    gradient buffer its consumers write into (each BN owns disjoint columns; the last consumer to
+    run its backward hands the complete buffer to autograd)."""
+
+    def __init__(self, gb: torch.Tensor, consumers: int):
+        self.gb, self.pending, self.grad = gb, consumers, None
+
+    def grad_buffer(self):
+        if self.grad is None:
+            self.grad = torch.zeros_like(self.gb)
+        return self.grad
+
+
+class BNFinalizeFn(torch.autograd.Function):
+    """ccbn: scale = rstd*(1+gain[n,c]), shift = bias[n,c] - mean*scale  (layers.py:656-689)."""
+
+    @staticmethod
+    def forward(ctx, stats, gb, bank, col_gain, col_bias, C, run_mean, run_var, count, eps, momentum, training):
+        N, ld = gb.shape
+        dev = gb.device
+        scale = torch.empty(N, C, dtype=torch.float32, device=dev)
+        shift = torch.empty(N, C, dtype=torch.float32, device=dev)
+        mr = torch.empty(2, C, dtype=torch.float32, device=dev)
+        H.call("ieagan_bn_finalize_fwd", H.ptr(stats), float(count), gb.data_ptr() + 4 * col_gain,
+               gb.data_ptr() + 4 * col_bias, ld, 1, float(eps), float(momentum), int(training), run_mean.data_ptr(),
+               run_var.data_ptr(), scale.data_ptr(), shift.data_ptr(), mr.data_ptr(), N, C, H.stream())
+        ctx.bank, ctx.cols, ctx.C, ctx.count, ctx.training = bank, (col_gain, col_bias), C, count, training
+        ctx.has_stats = stats is not None
+        ctx.save_for_backward(gb, mr)
+        return scale, shift
+
+    @staticmethod
+    def backward(ctx, dscale, dshift):
+        gb, mr = ctx.saved_tensors
+        N, ld = gb.shape
+        C = ctx.C
+        bank = ctx.bank
+        gbuf = bank.grad_buffer()
+        dstat = torch.empty(2, C, dtype=torch.float32, device=gb.device)
+        dscale = dscale.contiguous() if dscale is not None else torch.zeros(N, C, device=gb.device)
+        dshift = dshift.contiguous() if dshift is not None else torch.zeros(N, C, device=gb.device)
+        H.call("ieagan_bn_finalize_bwd", dscale.data_ptr(), dshift.data_ptr(), gb.data_ptr() + 4 * ctx.cols[0], ld, 1,
+               mr.data_ptr(), float(ctx.count), int(ctx.training), gbuf.data_ptr() + 4 * ctx.cols[0],
+               gbuf.data_ptr() + 4 * ctx.cols[1], ld, dstat.data_ptr(), N, C, H.stream())
+        bank.pending -= 1
+        dgb = gbuf if bank.pending == 0 else None
+        dstats = dstat.unsqueeze(0).expand(STAT_REPL, 2, C) if (ctx.has_stats and ctx.training) else None
+        return dstats, dgb, None, None, None, None, None, None, None, None, None, None
+
+
+class BNFinalizePlainFn(torch.autograd.Function):
+    """layers.bn: per-channel gain / bias parameters (layers.py:728-742)."""
+
+    @staticmethod
+    def forward(ctx, stats, gain, bias, run_mean, run_var, count, eps, momentum, training):
+        C = gain.numel()
+        dev = gain.device
+        scale = torch.empty(C, dtype=torch.float32, device=dev)
+        shift = torch.empty(C, dtype=torch.float32, device=dev)
+        mr = torch.empty(2, C, dtype=torch.float32, device=dev)
+        H.call("ieagan_bn_finalize_fwd", H.ptr(stats), float(count), gain.data_ptr(), bias.data_ptr(), 0, 0, float(eps),
+               float(momentum), int(training), run_mean.data_ptr(), run_var.data_ptr(), scale.data_ptr(),
+               shift.data_ptr(), mr.data_ptr(), 1, C, H.stream())
+        ctx.count, ctx.training, ctx.has_stats = count, training, stats is not None
+        ctx.save_for_backward(gain, mr)
+        return scale, shift
+
+    @staticmethod
+    def backward(ctx, dscale, dshift):
+        gain, mr = ctx.saved_tensors
+        C = gain.numel()
+        dev = gain.device
+        dgain, dbias = torch.empty_like(gain), torch.empty_like(gain)
+        dstat = torch.empty(2, C, dtype=torch.float32, device=dev)
+        dscale = dscale.contiguous() if dscale is not None else torch.zeros(C, device=dev)
+        dshift = dshift.contiguous() if dshift is not None else torch.zeros(C, device=dev)
+        H.call("ieagan_bn_finalize_bwd", dscale.data_ptr(), dshift.data_ptr(), gain.data_ptr(), 0, 0, mr.data_ptr(),
+               float(ctx.count), int(ctx.training), dgain.data_ptr(), dbias.data_ptr(), 0, dstat.data_ptr(), 1, C, H.stream())
+        dstats = dstat.unsqueeze(0).expand(STAT_REPL, 2, C) if (ctx.has_stats and ctx.training) else None
+        return dstats, dgain, dbias, None, None, None, None, None, None
+
+
+# =====================================================================================================
+# Fused convolution
+# =====================================================================================================
+def _conv_launch(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu, N, Hc, Wc, Cin, Cout, taps, kpad, w, bias,
+                 ra, Cra, Ca, ra_rs, rb, Crb, mask, out, stats):
+    d = H.ConvDesc(N, Hc, Wc, Cin, Cout, taps, kpad, H.src_desc(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu),
+                   H.ptr(w), H.ptr(bias), H.ptr(ra), Cra, Ca, ra_rs, H.ptr(rb), Crb, H.ptr(mask), H.ptr(out), H.ptr(stats))
+    H.call("ieagan_conv_forward", d, H.stream())
+
+
+USE_TR_READ = True        # ds_read_b64_tr_b16 operand reads in conv_wgrad (False: scalar LDS reads)
+
+
+class ConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, scale, shift, ra, rb, rec, taps, rs, relu, Ca, ra_rs, want_stats):
+        N, Hs, Ws, Cx = x.shape
+        Cout, Cin = rec.out, rec.cin
+        assert x.dtype == BF16 and x.is_contiguous() and Cx == Cin, (x.dtype, x.shape, Cin)
+        Hc, Wc = (2 * Hs, 2 * Ws) if rs == 1 else (Hs // 2, Ws // 2) if rs == 2 else (Hs, Ws)
+        out = torch.empty(N, Hc, Wc, Cout, dtype=BF16, device=x.device)
+        stats = new_stats(Cout, x.device) if want_stats else None
+        nstride = 0 if (scale is None or scale.dim() == 1) else scale.shape[1]
+        _conv_launch(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu, N, Hc, Wc, Cin, Cout, taps, rec.kpad, rec.w_fwd,
+                     bias, ra, ra.shape[-1] if ra is not None else 0, Ca, ra_rs, rb,
+                     rb.shape[-1] if rb is not None else 0, None, out, stats)
+        ctx.rec, ctx.cfg = rec, (taps, rs, relu, Ca, ra_rs, nstride, Hc, Wc)
+        ctx.ra_shape = ra.shape if ra is not None else None
+        ctx.has = (bias is not None, scale is not None, ra is not None, rb is not None)
+        ctx.save_for_backward(x, weight, scale, shift, out if want_stats else None)
+        ctx.mark_non_differentiable()
+        return out, stats
+
+    @staticmethod
+    def backward(ctx, dout, dstats):
+        x, weight, scale, shift, out = ctx.saved_tensors
+        rec = ctx.rec
+        taps, rs, relu, Ca, ra_rs, nstride, Hc, Wc = ctx.cfg
+        has_bias, has_aff, has_ra, has_rb = ctx.has
+        N, Hs, Ws, Cx = x.shape
+        Cout, Cin = rec.out, rec.cin
+        dev = x.device
+        need = ctx.needs_input_grad
+        g = dout.contiguous()
+        P = N * Hc * Wc
+        # ---- fold the batch-statistics path of the following BN into the out-grad; bias gradient
+        dbias = None
+        if dstats is not None:
+            geff = torch.empty_like(g)
+            colsum = torch.zeros(STAT_REPL, Cout, dtype=torch.float32, device=dev) if has_bias else None
+            H.call("ieagan_effgrad", g.data_ptr(), out.data_ptr(), dstats[0].contiguous().data_ptr(), geff.data_ptr(),
+                   H.ptr(colsum), P, Cout, H.stream())
+            g = geff
+        elif has_bias and need[2]:
+            colsum = torch.zeros(STAT_REPL, Cout, dtype=torch.float32, device=dev)
+            H.call("ieagan_effgrad", g.data_ptr(), None, None, None, colsum.data_ptr(), P, Cout, H.stream())
+        if has_bias and need[2]:
+            dbias = colsum.sum(0)
+        # ---- residual operands
+        d_ra = d_rb = None
+        if has_ra and need[5]:
+            rshape = ctx.ra_shape
+            if ra_rs == 0:
+                if Ca == Cout and rshape[-1] == Cout:
+                    d_ra = g
+                else:
+                    d_ra = torch.zeros(rshape, dtype=BF16, device=dev)
+                    d_ra[..., :Ca] = g[..., :Ca]
+            else:
+                d_ra = torch.empty(rshape, dtype=BF16, device=dev)
+                H.call("ieagan_res_bwd", g.data_ptr(), Cout, d_ra.data_ptr(), rshape[-1], Ca, ra_rs, N, rshape[1], rshape[2],
+                       H.stream())
+        if has_rb and need[6]:
+            d_rb = g[..., Ca:]
+        # ---- data gradient
+        dx = dscale = dshift = None
+        if need[0] or (has_aff and (need[3] or need[4])):
+            da = torch.empty(N, Hc, Wc, Cin, dtype=BF16, device=dev)
+            fuse_mask = relu and not has_aff and rs == 0
+            _conv_launch(g, Cout, Hc, Wc, 0, None, None, 0, False, N, Hc, Wc, Cout, Cin, taps, rec.kpad2, rec.w_bwd, None,
+                         None, 0, 0, 0, None, 0, x if fuse_mask else None, da, None)
+            if fuse_mask or (not relu and not has_aff and rs == 0):
+                dx = da
+            else:
+                dx = torch.empty(N, Hs, Ws, Cin, dtype=BF16, device=dev)
+                if has_aff:
+                    dscale = torch.zeros_like(scale)
+                    dshift = torch.zeros_like(shift)
+                H.call("ieagan_prologue_bwd", da.data_ptr(), x.data_ptr(), Cx, H.ptr(scale), H.ptr(shift), nstride, int(relu),
+                       rs, dx.data_ptr(), H.ptr(dscale), H.ptr(dshift), N, Hs, Ws, Cin, H.stream())
+        # ---- weight gradient (skipped entirely when the parameter is frozen, e.g. D in the G phase)
+        dW = None
+        if need[1]:
+            dwp = torch.zeros(Cout, rec.kpad, dtype=torch.float32, device=dev)
+            d = H.WgradDesc(N, Hc, Wc, Cin, Cout, taps, rec.kpad,
+                            H.src_desc(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu), g.data_ptr(), Cout, dwp.data_ptr(), 0)
+            H.call("ieagan_conv_wgrad", d, int(USE_TR_READ), H.stream())
+            dW = sn_backward(dwp, weight, rec)
+        return dx, dW, dbias, dscale, dshift, d_ra, d_rb, None, None, None, None, None, None, None
+
+
+def conv(x, weight, bias, rec, taps, *, scale=None, shift=None, relu=False, rs=0, ra=None, Ca=0, ra_rs=0, rb=None,
+         want_stats=False):
+    return ConvFn.apply(x, weight, bias, scale, shift, ra, rb, rec, taps, rs, relu, Ca, ra_rs, want_stats)
+
+
+# =====================================================================================================
+# single-channel-image convolutions
+# =====================================================================================================
+class InputConvFn(torch.autograd.Function):
+    """D.input_conv: fp32 image [N,1,H,W] -> bf16 NHWC [N,H,W,C]  (model.py:730, 905)."""
+
+    @staticmethod
+    def forward(ctx, img, weight, bias, rec):
+        N, _, Hh, Ww = img.shape
+        C = rec.out
+        img = img.contiguous().float()
+        out = torch.empty(N, Hh, Ww, C, dtype=BF16, device=img.device)
+        H.call("ieagan_conv_1toC", img.data_ptr(), None, rec.w_plain.data_ptr(), H.ptr(bias), out.data_ptr(), N, Hh, Ww, C, 0,
+               H.stream())
+        ctx.rec = rec
+        ctx.save_for_backward(img, weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        img, weight = ctx.saved_tensors
+        rec = ctx.rec
+        N, _, Hh, Ww = img.shape
+        C = rec.out
+        dev = img.device
+        g = dout.contiguous()
+        need = ctx.needs_input_grad
+        dimg = dW = dbias = None
+        if need[2]:
+            colsum = torch.zeros(STAT_REPL, C, dtype=torch.float32, device=dev)
+            H.call("ieagan_effgrad", g.data_ptr(), None, None, None, colsum.data_ptr(), N * Hh * Ww, C, H.stream())
+            dbias = colsum.sum(0)
+        if need[0]:
+            dimg = torch.empty(N, 1, Hh, Ww, dtype=torch.float32, device=dev)
+            H.call("ieagan_conv_Cto1", g.data_ptr(), None, None, 0, 0, rec.w_plain.data_ptr(), None, dimg.data_ptr(), 0, N, Hh,
+                   Ww, C, 1, H.stream())
+        if need[1]:
+            dw = torch.zeros(9, C, dtype=torch.float32, device=dev)
+            H.call("ieagan_wgrad_c1", img.data_ptr(), None, g.data_ptr(), None, None, 0, 0, dw.data_ptr(), N, Hh, Ww, C, 0,
+                   H.stream())
+            dW = sn_backward(dw, weight, rec)
+        return dimg, dW, dbias, None
+
+
+class OutputConvFn(torch.autograd.Function):
+    """G.output_layer: BN apply + ReLU + 3x3 conv (C -> 1) + tanh -> fp32 [N,1,H,W]  (model.py:379-387, 487)."""
+
+    @staticmethod
+    def forward(ctx, h, scale, shift, weight, bias, rec):
+        N, Hh, Ww, C = h.shape
+        y = torch.empty(N, 1, Hh, Ww, dtype=torch.float32, device=h.device)
+        H.call("ieagan_conv_Cto1", h.data_ptr(), scale.data_ptr(), shift.data_ptr(), 0, 1, rec.w_plain.data_ptr(), H.ptr(bias),
+               y.data_ptr(), 1, N, Hh, Ww, C, 0, H.stream())
+        ctx.rec = rec
+        ctx.save_for_backward(h, scale, shift, weight, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, scale, shift, weight, y = ctx.saved_tensors
+        rec = ctx.rec
+        N, Hh, Ww, C = h.shape
+        dev = h.device
+        need = ctx.needs_input_grad
+        dpre = (dy.contiguous().float() * (1.0 - y * y)).contiguous()          # tanh'
+        dh = dscale = dshift = dW = dbias = None
+        if need[4]:
+            dbias = dpre.sum().view(1)
+        if need[0] or need[1] or need[2]:
+            da = torch.empty(N, Hh, Ww, C, dtype=BF16, device=dev)
+            H.call("ieagan_conv_1toC", dpre.data_ptr(), None, rec.w_plain.data_ptr(), None, da.data_ptr(), N, Hh, Ww, C, 1,
+                   H.stream())
+            dh = torch.empty_like(h)
+            dscale, dshift = torch.zeros_like(scale), torch.zeros_like(shift)
+            H.call("ieagan_prologue_bwd", da.data_ptr(), h.data_ptr(), C, scale.data_ptr(), shift.data_ptr(), 0, 1, 0,
+                   dh.data_ptr(), dscale.data_ptr(), dshift.data_ptr(), N, Hh, Ww, C, H.stream())
+        if need[3]:
+            dw = torch.zeros(9, C, dtype=torch.float32, device=dev)
+            H.call("ieagan_wgrad_c1", dpre.data_ptr(), None, h.data_ptr(), scale.data_ptr(), shift.data_ptr(), 0, 1, dw.data_ptr(),
+                   N, Hh, Ww, C, 1, H.stream())
+            dW = sn_backward(dw, weight, rec)
+        return dh, dscale, dshift, dW, dbias, None
+
+
+# =====================================================================================================
+# module-boundary layout changes
+# =====================================================================================================
+class ToNHWCFn(torch.autograd.Function):
+    """fp32 NCHW -> bf16 NHWC (+ batch statistics of the result)."""
+
+    @staticmethod
+    def forward(ctx, x, want_stats):
+        N, C, Hh, Ww = x.shape
+        x = x.contiguous().float()
+        out = torch.empty(N, Hh, Ww, C, dtype=BF16, device=x.device)
+        stats = new_stats(C, x.device) if want_stats else None
+        H.call("ieagan_nchw_to_nhwc", x.data_ptr(), out.data_ptr(), H.ptr(stats), N, C, Hh * Ww, H.stream())
+        ctx.save_for_backward(out if want_stats else None)
+        return out, stats
+
+    @staticmethod
+    def backward(ctx, dout, dstats):
+        (out,) = ctx.saved_tensors
+        g = dout.contiguous()
+        N, Hh, Ww, C = g.shape
+        if dstats is not None:
+            geff = torch.empty_like(g)
+            H.call("ieagan_effgrad", g.data_ptr(), out.data_ptr(), dstats[0].contiguous().data_ptr(), geff.data_ptr(), None,
+                   N * Hh * Ww, C, H.stream())
+            g = geff
+        dx = torch.empty(N, C, Hh, Ww, dtype=torch.float32, device=g.device)
+        H.call("ieagan_nhwc_to_nchw", g.data_ptr(), dx.data_ptr(), N, C, Hh * Ww, H.stream())
+        return dx, None
+
+
+class ToNCHWFn(torch.autograd.Function):
+    """bf16 NHWC -> fp32 NCHW."""
+
+    @staticmethod
+    def forward(ctx, x):
+        N, Hh, Ww, C = x.shape
+        out = torch.empty(N, C, Hh, Ww, dtype=torch.float32, device=x.device)
+        H.call("ieagan_nhwc_to_nchw", x.contiguous().data_ptr(), out.data_ptr(), N, C, Hh * Ww, H.stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        N, C, Hh, Ww = g.shape
+        dx = torch.empty(N, Hh, Ww, C, dtype=BF16, device=g.device)
+        H.call("ieagan_nchw_to_nhwc", g.contiguous().float().data_ptr(), dx.data_ptr(), None, N, C, Hh * Ww, H.stream())
+        return dx
+
+
+def channel_stats(x: torch.Tensor) -> torch.Tensor:
+    """(sum, sumsq) of a bf16 NHWC tensor (no autograd; for tensors not produced by a conv)."""
+    C = x.shape[-1]
+    st = new_stats(C, x.device)
+    H.call("ieagan_channel_stats", x.data_ptr(), st.data_ptr(), x.numel() // C, C, H.stream())
+    return st
+
+
+# =====================================================================================================
+# augmentation
+# =====================================================================================================
+class DiffAugFn(torch.autograd.Function):
+    """DiffAugment('color,translation,cutout') on single-channel fp32 events (diff_aug.py:10-109)."""
+
+    @staticmethod
+    def forward(ctx, x, bright, contrast, tx, ty, ox, oy):
+        N, C, Hh, Ww = x.shape
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        sums = torch.zeros(N, dtype=torch.float32, device=x.device)
+        H.call("ieagan_diffaug_fwd", x.data_ptr(), bright.data_ptr(), contrast.data_ptr(), tx.data_ptr(), ty.data_ptr(),
+               ox.data_ptr(), oy.data_ptr(), sums.data_ptr(), out.data_ptr(), N, Hh, Ww, H.stream())
+        ctx.save_for_backward(contrast, tx, ty, ox, oy)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        contrast, tx, ty, ox, oy = ctx.saved_tensors
+        N, C, Hh, Ww = g.shape
+        g = g.contiguous()
+        gx = torch.empty_like(g)
+        gs = torch.zeros(N, dtype=torch.float32, device=g.device)
+        H.call("ieagan_diffaug_bwd", g.data_ptr(), contrast.data_ptr(), tx.data_ptr(), ty.data_ptr(), ox.data_ptr(),
+               oy.data_ptr(), gs.data_ptr(), gx.data_ptr(), N, Hh, Ww, H.stream())
+        return gx, None, None, None, None, None, None
+
+
+def cr_diffaug(x, flip_u, tx, ty):
+    N, C, Hh, Ww = x.shape
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    H.call("ieagan_cr_diffaug", x.data_ptr(), flip_u.data_ptr(), tx.data_ptr(), ty.data_ptr(), out.data_ptr(), N, Hh, Ww,
+           H.stream())
+    return out

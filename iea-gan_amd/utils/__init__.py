@@ -1,0 +1,134 @@
+"""Train-step utilities behind the reference's ``utils`` surface (reference ``utils/__init__.py``:
+Distribution 41-120, prepare_z_y 124-158, seed_rng 218-226, toggle_grad 261-263, make_mask 266-275,
+apply_ema 809-837, ortho 843-859).  Host-side bookkeeping of the reference (sample sheets, plots,
+Inception statistics) is out of scope of the MI355X hot path.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+import _hip as H
+
+
+class Distribution(torch.Tensor):
+    """Latent / label holder refilled in place by ``sample_()``."""
+
+    def init_distribution(self, dist_type: str, **kwargs):
+        self.dist_type, self.dist_kwargs = dist_type, kwargs
+        if dist_type in ("normal", "censored_normal"):
+            self.mean, self.var = kwargs["mean"], kwargs["var"]
+        elif dist_type in ("categorical", "permuted"):
+            self.num_categories = kwargs["num_categories"]
+        elif dist_type != "bernoulli":
+            raise NotImplementedError(f"Distribution '{dist_type}' is not implemented")
+
+    def sample_(self):
+        if self.dist_type == "normal":
+            self.normal_(self.mean, self.var)
+        elif self.dist_type == "censored_normal":
+            self.normal_(self.mean, self.var)
+            self.relu_()
+        elif self.dist_type == "categorical":
+            self.random_(0, self.num_categories)
+        elif self.dist_type == "bernoulli":
+            self.bernoulli_()
+        elif self.dist_type == "permuted":
+            self.copy_(torch.randperm(self.num_categories, device=self.device))
+        else:
+            raise NotImplementedError(f"Distribution '{self.dist_type}' is not implemented")
+
+    def to(self, *args, **kwargs):
+        new_obj = Distribution(self)
+        new_obj.init_distribution(self.dist_type, **self.dist_kwargs)
+        new_obj.data = super().to(*args, **kwargs)
+        return new_obj
+
+
+def prepare_z_y(G_batch_size, dim_z, nclasses, device="cuda", fp16=False, z_var=1.0, z_dist="normal", threshold=1,
+                y_dist="permuted", ngd=False, fixed=False):
+    if ngd or fp16:
+        raise NotImplementedError("prepare_z_y: ngd / fp16 latents are not part of the MI355X path")
+    z_ = Distribution(torch.randn(G_batch_size, dim_z, requires_grad=False))
+    if z_dist in ("normal", "censored_normal"):
+        z_.init_distribution(z_dist, mean=0, var=z_var)
+    elif z_dist == "bernoulli":
+        z_.init_distribution(z_dist)
+    else:
+        raise NotImplementedError(f"z_dist {z_dist}")
+    z_ = z_.to(device, torch.float32)
+    y_ = Distribution(torch.zeros(G_batch_size, requires_grad=False))
+    y_.init_distribution("categorical" if y_dist == "categorical" else "permuted", num_categories=nclasses, device=device)
+    y_ = y_.to(device, torch.int64)
+    return z_, y_
+
+
+def seed_rng(seed):
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(seed)
+    np.random.seed(seed)
+
+
+def toggle_grad(model, on_or_off):
+    for p in model.parameters():
+        p.requires_grad = on_or_off
+
+
+def make_mask(labels, n_cls, device):
+    """[n_cls, n_samples] one-hot of the labels, built on the device (no host round trip)."""
+    return (torch.arange(n_cls, device=labels.device)[:, None] == labels[None, :]).to(torch.long).to(device)
+
+
+class apply_ema(object):
+    """EMA of ``source`` into ``target`` over every state-dict entry (parameters AND buffers): one fused
+    launch over the two flat arenas."""
+
+    def __init__(self, source, target, decay=0.9999, start_itr=0):
+        self.source, self.target, self.decay, self.start_itr = source, target, decay, start_itr
+        print("Initializing EMA parameters to be source parameters...")
+        with torch.no_grad():
+            tgt = self.target.state_dict()
+            for k, v in self.source.state_dict().items():
+                tgt[k].copy_(v)
+
+    def _arenas(self):
+        from arena import Arena
+        out = []
+        for net in (self.source, self.target):
+            a = net.__dict__.get("_arena")
+            probe = next(net.parameters())
+            if a is None or a.root is not net or not a.contains(probe):
+                a = Arena(net)
+                if hasattr(net, "_plan"):
+                    net._plan = None
+            out.append(a)
+        return out
+
+    def update(self, itr=None):
+        decay = 0.0 if (itr and itr < self.start_itr) else self.decay
+        H.require_gpu()
+        src, tgt = self._arenas()
+        assert src.flat.numel() == tgt.flat.numel(), "EMA source / target layouts differ"
+        H.call("ieagan_ema_update", tgt.flat.data_ptr(), src.flat.data_ptr(), src.flat.numel(), float(decay), H.stream())
+
+
+def ortho(model, strength=1e-4, blacklist=None):
+    """Modified orthogonal regularisation added straight to ``param.grad``:
+    2*strength * ((W W^T) (.) (1 - I)) W, evaluated as W (W^T W) - diag(|w_i|^2) W so that the Gram
+    matrix is [in, in] (256x256 for G.linear) instead of [out, out] (24576x24576 in the reference)."""
+    blacklist = blacklist or []
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.dim() < 2 or any(p is b for b in blacklist) or p.grad is None:
+                continue
+            w = p.view(p.shape[0], -1)
+            if w.shape[0] <= w.shape[1]:
+                g = torch.mm(torch.mm(w, w.t()).fill_diagonal_(0.0), w)
+            else:
+                g = torch.mm(w, torch.mm(w.t(), w)) - (w * w).sum(1, keepdim=True) * w
+            p.grad.add_(g.view(p.shape), alpha=2 * strength)
+
+
+def count_parameters(module):
+    print("Number of parameters: {}".format(sum(p.data.nelement() for p in module.parameters())))

@@ -1,0 +1,132 @@
+/* C ABI of libieagan_hip.so -- the MI355X (gfx950) kernels behind the IEA-GAN G+D train step.
+ *
+ * Conventions: every entry point is `extern "C"`, takes plain pointers and
+ * sizes, enqueues its work on the given hipStream_t (passed as void*), never allocates device
+ * memory, never synchronises and never changes the current device.  The caller (the PyTorch caching
+ * allocator on the Python side) owns every buffer.  Return value: 0 on success, negative on error;
+ * `ieagan_last_error()` returns a thread-local description.  Functions are re-entrant (forward runs
+ * on the Python main thread, backward on the autograd thread).
+ *
+ * Activations are bf16 NHWC; parameters, statistics and accumulators are fp32.  The reference has no
+ * native interface (it is pure PyTorch): each entry point cites the reference ATen op sequence it
+ * replaces (paths relative to the reference repository root).
+ */
+#ifndef IEAGAN_HIP_H
+#define IEAGAN_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* ieagan_last_error(void);
+int ieagan_abi_version(void);
+
+/* ---- profiling hooks (bench.py): per-kernel HIP-event timing on the launch stream ---- */
+int ieagan_prof_enable(int on);          /* 1: bracket every launch with hipEvents; 0: off     */
+int ieagan_prof_reset(void);
+/* Writes up to `cap` records {name[48], launches, ms, flops, bytes}; returns the record count.   */
+typedef struct { char name[48]; long launches; double ms; double flops; double bytes; } ieagan_prof_rec;
+int ieagan_prof_collect(ieagan_prof_rec* out, int cap);
+
+/* ---- source operand of a convolution with its fused prologue --------------------------------
+ * Replaces, in front of F.conv2d: ccbn / bn apply (layers.py:656-689, 728-742), ReLU,
+ * F.interpolate(scale_factor=2) (model.py:60-65) and nn.AvgPool2d(2) (model.py:553-554, 535-536). */
+typedef struct {
+    const void* x;        /* bf16 [N, Hs, Ws, Cx]                                              */
+    int Cx, Hs, Ws;
+    int rs;               /* 0 same resolution | 1 nearest x2 upsample of x | 2 2x2 average pool */
+    const float* scale;   /* per-(n,c) BN scale  rstd*(1+gain)   or NULL                        */
+    const float* shift;   /* per-(n,c) BN shift  bias - mean*scale                              */
+    int aff_nstride;      /* image stride of scale/shift (0: per-channel only)                  */
+    int relu;
+} ieagan_src_desc;
+
+/* ---- implicit-GEMM convolution (forward, and dgrad with the transposed pack) -----------------
+ * Replaces SNConv2d.forward = F.conv2d(x, W/sigma, bias, 1, pad) (layers.py:197-206) together with
+ * the residual add / channel-dropped shortcut / concat shortcut of GBlock and DBlock
+ * (model.py:60-71, 534-557) and the statistics pass of the following batch norm. */
+typedef struct {
+    int N, H, W;          /* output (= conv) resolution                                         */
+    int Cin, Cout, taps;  /* taps 1 (1x1, pad 0) or 9 (3x3, pad 1)                              */
+    int Kpad;             /* weight-pack row length, multiple of 32                             */
+    ieagan_src_desc src;
+    const void* w;        /* bf16 [Cout][Kpad], k = tap*Cin + c  (from ieagan_sn_forward)       */
+    const float* bias;    /* [Cout] or NULL                                                     */
+    const void* ra;       /* residual A: bf16, channels [0,Ca) of a tensor with Cra channels    */
+    int Cra, Ca, ra_rs;   /* ra_rs 0 same | 1 residual at half res | 2 residual at double res   */
+    const void* rb;       /* residual B: bf16 [N,H,W,Crb] feeding channels [Ca, Cout)           */
+    int Crb;
+    const void* mask;     /* bf16 [N,H,W,Cout]: output zeroed where mask <= 0, or NULL          */
+    void* out;            /* bf16 [N,H,W,Cout]                                                  */
+    float* stats;         /* fp32 [32][2][Cout] replicated (sum, sumsq), accumulated; or NULL   */
+} ieagan_conv_desc;
+int ieagan_conv_forward(const ieagan_conv_desc* d, void* stream);
+
+/* ---- weight gradient: dWp[Cout][Kpad] += G^T A   (autograd of F.conv2d w.r.t. weight) -------- */
+typedef struct {
+    int N, H, W;
+    int Cin, Cout, taps, Kpad;
+    ieagan_src_desc src;  /* the forward's A operand (same prologue)                            */
+    const void* g;        /* bf16 gradient w.r.t. the conv output, channels [0,Cout) of Cg      */
+    int Cg;
+    float* dw;            /* fp32 [Cout][Kpad], caller zeroes                                   */
+    int tiles_per_block;  /* filled by the launcher                                             */
+} ieagan_wgrad_desc;
+int ieagan_conv_wgrad(const ieagan_wgrad_desc* d, int use_tr_read, void* stream);
+
+/* ---- element-wise companions (bn_elem.hip) ---------------------------------------------------- */
+/* g_eff = dout + dsum[c] + 2*out*dsumsq[c]; colsum[32][C] += column sums (bias gradient).
+ * Autograd of F.batch_norm's batch statistics folded into the producer's out-grad. */
+int ieagan_effgrad(const void* dout, const void* out, const float* dstat, void* geff, float* colsum,
+                   long P, int C, void* stream);
+/* backward of the fused prologue: dx, and per-(n,c) d scale / d shift (atomically accumulated) */
+int ieagan_prologue_bwd(const void* da, const void* x, int Cx, const float* scale, const float* shift,
+                        int nstride, int relu, int rs, void* dx, float* dscale, float* dshift,
+                        int N, int Hs, int Ws, int C, void* stream);
+/* ccbn / bn statistics -> scale/shift (+ running-stat update), layers.py:656-689, 728-742 */
+int ieagan_bn_finalize_fwd(const float* stats, float count, const float* gain, const float* bias, int ld,
+                           int plus_one, float eps, float momentum, int training, float* run_mean,
+                           float* run_var, float* scale, float* shift, float* mean_rstd, int N, int C,
+                           void* stream);
+int ieagan_bn_finalize_bwd(const float* dscale, const float* dshift, const float* gain, int ld, int plus_one,
+                           const float* mean_rstd, float count, int training, float* dgain, float* dbias,
+                           int ldd, float* dstat, int N, int C, void* stream);
+int ieagan_res_bwd(const void* g, int Cg, void* dr, int Cr, int Ca, int mode, int N, int Hr, int Wr, void* stream);
+int ieagan_nchw_to_nhwc(const float* in, void* out, float* stats, int N, int C, int HW, void* stream);
+int ieagan_nhwc_to_nchw(const void* in, float* out, int N, int C, int HW, void* stream);
+int ieagan_channel_stats(const void* x, float* stats, long P, int C, void* stream);
+
+/* ---- single-channel-image convolutions (conv_c1.hip): D.input_conv (model.py:730, 905) and
+ * G.output_layer = bn + relu + conv + tanh (model.py:379-387, 487) -------------------------------- */
+int ieagan_conv_1toC(const float* img, const float* tanh_y, const float* w, const float* bias, void* out,
+                     int N, int H, int W, int C, int flip, void* stream);
+int ieagan_conv_Cto1(const void* x, const float* scale, const float* shift, int nstride, int relu,
+                     const float* w, const float* bias, float* out, int tanh_out, int N, int H, int W, int C,
+                     int flip, void* stream);
+int ieagan_wgrad_c1(const float* img, const float* tanh_y, const void* t, const float* scale, const float* shift,
+                    int nstride, int relu, float* dw, int N, int H, int W, int C, int flip, void* stream);
+
+/* ---- batched spectral norm (sn.hip): layers.SN.W_ / power_iteration (layers.py:89-165) -------- */
+int ieagan_sn_forward(const long* table, const int* blocks, int nblocks, float* params, float* ctx, void* pack,
+                      float eps, int training, void* stream);
+int ieagan_sn_backward(const float* gsn, const float* W, int kind, int out, int in, int taps, int cin, int kpad,
+                       const float* ctx, float* inner_scratch, float* dW, void* stream);
+
+/* ---- augmentation + optimiser (aug_optim.hip) -------------------------------------------------- */
+int ieagan_diffaug_fwd(const float* x, const float* bright, const float* contrast, const long* tx, const long* ty,
+                       const long* ox, const long* oy, float* sums, float* out, int N, int H, int W, void* stream);
+int ieagan_diffaug_bwd(const float* gout, const float* contrast, const long* tx, const long* ty, const long* ox,
+                       const long* oy, float* gsums, float* gx, int N, int H, int W, void* stream);
+int ieagan_cr_diffaug(const float* x, const float* flip_u, const long* tx, const long* ty, float* out, int N,
+                      int H, int W, void* stream);
+int ieagan_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                     int step, float gscale, void* stream);
+int ieagan_ema_update(float* tgt, const float* src, long n, float decay, void* stream);
+
+/* ---- self-test of the transposed LDS read used by conv_wgrad (tests only) ---------------------- */
+int ieagan_selftest_tr_read(const void* in_bf16_64x16, void* out_bf16_64x8, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

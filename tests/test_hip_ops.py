@@ -1,0 +1,351 @@
+"""Per-operator parity of the HIP kernels (through the C ABI / ops.py) on a real MI355X.
+
+Checker: plain fp32 PyTorch of the same operator on the same bf16-rounded inputs (and, for the
+module-level cases, the reference-generated golden vectors in tests/golden/).  bf16 tolerance: outputs
+are rounded to bf16 (8 mantissa bits) and the A operand is re-rounded after the fused prologue, so the
+bound is 1.5e-2 * max|ref| per element (tighter for fp32-in/fp32-out kernels).
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import _hip
+    _hip.require_gpu()
+    _hip.lib()
+    return torch.device("cuda:0")
+
+
+def close(a, b, tol, what=""):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert torch.isfinite(a).all(), f"{what}: non-finite values"
+    err = (a - b).abs().max().item()
+    scale = max(b.abs().max().item(), 1e-3)
+    assert err <= tol * scale, f"{what}: max|diff|={err:.4e} vs scale {scale:.4e} (tol {tol})"
+
+
+def r16(t):
+    return t.to(BF).float()
+
+
+def nhwc(t):   # NCHW fp32 -> NHWC bf16 contiguous
+    return t.permute(0, 2, 3, 1).contiguous().to(BF)
+
+
+def nchw(t):   # NHWC -> NCHW fp32
+    return t.float().permute(0, 3, 1, 2).contiguous()
+
+
+def sn_ref(W, u, eps=1e-6):
+    Wm = W.reshape(W.shape[0], -1)
+    with torch.no_grad():
+        v = F.normalize(u @ Wm, eps=eps)
+        u2 = F.normalize(v @ Wm.t(), eps=eps)
+    sigma = ((v @ Wm.t()) @ u2.t()).squeeze()
+    return W / sigma, u2, sigma
+
+
+def make_rec(W, u, sv, kind=None):
+    """Run the batched SN kernel on a tiny private arena holding (W, u, sv)."""
+    import ops
+    flat = torch.cat([W.reshape(-1), u.reshape(-1), sv.reshape(-1)]).contiguous()
+    Wv = flat[:W.numel()].view(W.shape)
+    uv = flat[W.numel():W.numel() + u.numel()].view(u.shape)
+    svv = flat[W.numel() + u.numel():].view(sv.shape)
+    if kind is None:
+        kind = ops.KIND_CONV if W.dim() == 4 else ops.KIND_PLAIN
+    bank = ops.SNBank(flat, [("l", kind, Wv, uv, svv)])
+    rec = bank.run(True, 1e-6)["l"]
+    return rec, Wv, uv, svv
+
+
+def test_tr_read_selftest(dev):
+    """ds_read_b64_tr_b16 delivers the MFMA B fragment the wgrad kernel assumes."""
+    import _hip
+    src = torch.arange(64 * 16, device=dev, dtype=torch.float32).view(64, 16).to(BF)
+    out = torch.zeros(64, 8, device=dev, dtype=BF)
+    _hip.call("ieagan_selftest_tr_read", src.data_ptr(), out.data_ptr(), _hip.stream())
+    torch.cuda.synchronize()
+    lanes = torch.arange(64, device=dev)
+    exp = torch.stack([src[8 * (lanes >> 4) + j, lanes & 15] for j in range(8)], 1)
+    assert torch.equal(out, exp), (out[:20], exp[:20])
+
+
+@pytest.mark.parametrize("out_f,in_shape", [(48, (32, 3, 3)), (16, (64, 1, 1)), (128, (132,)), (40, (1024,)), (24576, (256,))])
+def test_sn_forward_backward(dev, out_f, in_shape):
+    import ops
+    torch.manual_seed(0)
+    W = (torch.randn(out_f, *in_shape, device=dev) / math.sqrt(np.prod(in_shape))).requires_grad_(True)
+    u = torch.randn(1, out_f, device=dev)
+    rec, Wv, uv, svv = make_rec(W.detach(), u, torch.ones(1, device=dev))
+    Wsn, u2, sigma = sn_ref(W, u)
+    close(rec.ctx[0:1], sigma.view(1), 1e-5, "sigma")
+    close(uv, u2, 1e-4, "u update")
+    close(svv, sigma.view(1), 1e-5, "sv")
+    inn = int(np.prod(in_shape))
+    if rec.kind == ops.KIND_CONV:
+        taps, cin = rec.taps, rec.cin
+        exp = Wsn.detach().view(out_f, cin, taps).permute(0, 2, 1).reshape(out_f, taps * cin)
+        close(rec.w_fwd[:, :taps * cin], exp, 1e-2, "fwd pack")
+        assert float(rec.w_fwd[:, taps * cin:].float().abs().sum()) == 0.0
+        expb = Wsn.detach().view(out_f, cin, taps).flip(2).permute(1, 2, 0).reshape(cin, taps * out_f)
+        close(rec.w_bwd[:, :taps * out_f], expb, 1e-2, "dgrad pack")
+        g = torch.randn(out_f, rec.kpad, device=dev)
+        g[:, taps * cin:] = 0
+        g_param = g[:, :taps * cin].view(out_f, taps, cin).permute(0, 2, 1).reshape(W.shape)
+    else:
+        close(rec.w_plain, Wsn.detach().view(out_f, inn), 1e-5, "plain pack")
+        g = torch.randn(out_f, inn, device=dev)
+        g_param = g.view(W.shape)
+    (ref,) = torch.autograd.grad(Wsn, [W], g_param)
+    got = ops.sn_backward(g.contiguous(), Wv, rec)
+    close(got, ref, 1e-4, "sn backward")
+
+
+CONV_CASES = [
+    # taps Cin Cout H  W  aff   relu  rs residual            stats
+    (9, 32, 48, 10, 14, False, False, 0, None, False),
+    (9, 16, 16, 12, 20, True, True, 0, None, True),
+    (9, 64, 64, 6, 10, True, True, 1, None, True),          # upsampled source (GBlock.conv2)
+    (9, 128, 128, 4, 12, False, True, 0, None, False),
+    (1, 64, 16, 9, 7, True, True, 0, None, True),
+    (1, 16, 64, 8, 12, True, True, 0, ("same", 64, 64), True),   # GBlock.conv4, same resolution
+    (1, 16, 32, 8, 12, True, True, 0, ("up", 64, 32), True),     # GBlock.conv4 + upsampled, channel-dropped shortcut
+    (1, 16, 64, 4, 6, False, True, 2, ("pool+sc", 32, 32), False),  # DBlock.conv4 + pooled concat shortcut
+    (1, 32, 32, 4, 6, False, False, 2, None, False),             # DBlock.conv_sc on the pooled input
+    (1, 512, 128, 4, 12, True, True, 0, None, True),
+    (1, 128, 512, 4, 12, False, True, 0, None, False),
+]
+
+
+def conv_reference(x, W, u, bias, scale, shift, relu, rs, taps, ra, ra_mode, Ca, rb):
+    """fp32 NCHW composite with the kernel's rounding points (A operand and weights in bf16)."""
+    a = x
+    if scale is not None:
+        a = a * scale[:, :, None, None] + shift[:, :, None, None]
+    if relu:
+        a = F.relu(a)
+    if rs == 1:
+        a = F.interpolate(a, scale_factor=2)
+    elif rs == 2:
+        a = F.avg_pool2d(a, 2)
+    a = a + (r16(a) - a).detach()          # straight-through bf16 rounding of the MFMA operand
+    Wsn, _, _ = sn_ref(W, u)
+    Wq = Wsn + (r16(Wsn) - Wsn).detach()
+    out = F.conv2d(a, Wq, bias, 1, 1 if taps == 9 else 0)
+    if ra is not None:
+        r = ra[:, :Ca]
+        if ra_mode == 1:
+            r = F.interpolate(r, scale_factor=2)
+        elif ra_mode == 2:
+            r = F.avg_pool2d(r, 2)
+        if rb is not None:
+            r = torch.cat([r, rb], 1)
+        elif Ca < out.shape[1]:
+            r = F.pad(r, (0, 0, 0, 0, 0, out.shape[1] - Ca))
+        out = out + r
+    return out
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[f"c{i}" for i in range(len(CONV_CASES))])
+def test_conv_forward_backward(dev, case):
+    import ops
+    taps, Cin, Cout, Hs, Ws, aff, relu, rs, res, stats = case
+    torch.manual_seed(1)
+    N = 3
+    k = 3 if taps == 9 else 1
+    x = r16(torch.randn(N, Cin, Hs, Ws, device=dev)).requires_grad_(True)
+    W = (torch.randn(Cout, Cin, k, k, device=dev) / math.sqrt(Cin * taps)).requires_grad_(True)
+    u = torch.randn(1, Cout, device=dev)
+    bias = (0.1 * torch.randn(Cout, device=dev)).requires_grad_(True)
+    scale = shift = None
+    if aff:
+        scale = (1 + 0.3 * torch.randn(N, Cin, device=dev)).requires_grad_(True)
+        shift = (0.2 * torch.randn(N, Cin, device=dev)).requires_grad_(True)
+    Hc, Wc = (2 * Hs, 2 * Ws) if rs == 1 else (Hs // 2, Ws // 2) if rs == 2 else (Hs, Ws)
+    ra = rb = None
+    ra_mode, Ca = 0, 0
+    if res is not None:
+        kind, Cra, Ca = res
+        if kind == "same":
+            ra = r16(torch.randn(N, Cra, Hc, Wc, device=dev)).requires_grad_(True)
+        elif kind == "up":
+            ra, ra_mode = r16(torch.randn(N, Cra, Hc // 2, Wc // 2, device=dev)).requires_grad_(True), 1
+        else:
+            ra, ra_mode = r16(torch.randn(N, Cra, 2 * Hc, 2 * Wc, device=dev)).requires_grad_(True), 2
+            rb = r16(torch.randn(N, Cout - Ca, Hc, Wc, device=dev)).requires_grad_(True)
+    ref = conv_reference(x, W, u, bias, scale, shift, relu, rs, taps, ra, ra_mode, Ca, rb)
+    go = r16(torch.randn_like(ref))
+    # reference statistics path: loss also depends on sum / sumsq of the output
+    dsum = 0.05 * torch.randn(2, Cout, device=dev)
+    loss_ref = (ref * go).sum()
+    if stats:
+        loss_ref = loss_ref + (ref.sum((0, 2, 3)) * dsum[0]).sum() + ((ref * ref).sum((0, 2, 3)) * dsum[1]).sum()
+    leaves = [t for t in (x, W, bias, scale, shift, ra, rb) if t is not None]
+    grads_ref = torch.autograd.grad(loss_ref, leaves)
+
+    # ---- HIP path
+    rec, Wv, uv, svv = make_rec(W.detach(), u, torch.ones(1, device=dev))
+    Wp = Wv.detach().requires_grad_(True)
+    xa = nhwc(x.detach()).requires_grad_(True)
+    b2 = bias.detach().clone().requires_grad_(True)
+    sc2 = scale.detach().clone().requires_grad_(True) if aff else None
+    sh2 = shift.detach().clone().requires_grad_(True) if aff else None
+    ra2 = nhwc(ra.detach()).requires_grad_(True) if ra is not None else None
+    rb2 = nhwc(rb.detach()).requires_grad_(True) if rb is not None else None
+    out, st = ops.conv(xa, Wp, b2, rec, taps, scale=sc2, shift=sh2, relu=relu, rs=rs, ra=ra2, Ca=Ca, ra_rs=ra_mode, rb=rb2,
+                       want_stats=stats)
+    close(nchw(out), ref, 1.5e-2, "conv out")
+    loss = (out.float() * nhwc(go).float()).sum()
+    if stats:
+        ssum = st.sum(0)
+        close(ssum[0], ref.sum((0, 2, 3)), 2e-2, "stat sum")
+        close(ssum[1], (ref * ref).sum((0, 2, 3)), 2e-2, "stat sumsq")
+        loss = loss + (st.sum(0) * dsum).sum()
+    leaves2 = [t for t in (xa, Wp, b2, sc2, sh2, ra2, rb2) if t is not None]
+    grads = torch.autograd.grad(loss, leaves2)
+    names = [n for n, t in zip(("x", "W", "bias", "scale", "shift", "ra", "rb"), (x, W, bias, scale, shift, ra, rb)) if t is not None]
+    for n, g, gr in zip(names, grads, grads_ref):
+        if n in ("x", "ra", "rb"):
+            g = nchw(g)
+        close(g, gr, 3e-2, f"grad {n}")
+
+
+def test_wgrad_tr_vs_scalar_reads(dev):
+    """The transposed-read operand path and the scalar-read reference path agree bit for bit in fp32 sums
+    up to atomic ordering."""
+    import _hip, ops
+    torch.manual_seed(3)
+    N, Hh, Ww, Cin, Cout = 2, 16, 32, 32, 48
+    x = torch.randn(N, Hh, Ww, Cin, device=dev).to(BF)
+    g = torch.randn(N, Hh, Ww, Cout, device=dev).to(BF)
+    outs = []
+    for tr in (1, 0):
+        dw = torch.zeros(Cout, 9 * Cin, device=dev)
+        d = _hip.WgradDesc(N, Hh, Ww, Cin, Cout, 9, 9 * Cin, _hip.src_desc(x, Cin, Hh, Ww), g.data_ptr(), Cout, dw.data_ptr(), 0)
+        _hip.call("ieagan_conv_wgrad", d, tr, _hip.stream())
+        outs.append(dw)
+    ref = torch.nn.grad.conv2d_weight(nchw(x), (Cout, Cin, 3, 3), nchw(g), padding=1)
+    ref = ref.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin)
+    close(outs[1], ref, 2e-3, "scalar-read wgrad")
+    close(outs[0], ref, 2e-3, "tr-read wgrad")
+
+
+@pytest.mark.parametrize("C,Hh,Ww", [(32, 20, 28), (16, 9, 13)])
+def test_single_channel_convs(dev, C, Hh, Ww):
+    import ops
+    torch.manual_seed(4)
+    N = 3
+    # ---- D.input_conv: image -> C channels
+    img = torch.randn(N, 1, Hh, Ww, device=dev, requires_grad=True)
+    W = (torch.randn(C, 1, 3, 3, device=dev) / 3).requires_grad_(True)
+    u = torch.randn(1, C, device=dev)
+    bias = (0.1 * torch.randn(C, device=dev)).requires_grad_(True)
+    Wsn, _, _ = sn_ref(W, u)
+    ref = F.conv2d(img, Wsn, bias, 1, 1)
+    go = r16(torch.randn_like(ref))
+    gref = torch.autograd.grad((ref * go).sum(), [img, W, bias])
+    rec, Wv, _, _ = make_rec(W.detach(), u, torch.ones(1, device=dev), kind=ops.KIND_C1_IN)
+    img2 = img.detach().clone().requires_grad_(True)
+    Wp = Wv.detach().requires_grad_(True)
+    b2 = bias.detach().clone().requires_grad_(True)
+    out = ops.InputConvFn.apply(img2, Wp, b2, rec)
+    close(nchw(out), ref, 1e-2, "input conv")
+    g = torch.autograd.grad((out.float() * nhwc(go).float()).sum(), [img2, Wp, b2])
+    for n, a, b in zip(("img", "W", "bias"), g, gref):
+        close(a, b, 2e-2, f"input conv grad {n}")
+    # ---- G.output_layer: bn apply + relu + conv (C -> 1) + tanh
+    h = r16(torch.randn(N, C, Hh, Ww, device=dev)).requires_grad_(True)
+    W = (torch.randn(1, C, 3, 3, device=dev) / math.sqrt(9 * C)).requires_grad_(True)
+    u = torch.randn(1, 1, device=dev)
+    bias = (0.1 * torch.randn(1, device=dev)).requires_grad_(True)
+    scale = (1 + 0.3 * torch.randn(C, device=dev)).requires_grad_(True)
+    shift = (0.2 * torch.randn(C, device=dev)).requires_grad_(True)
+    Wsn, _, _ = sn_ref(W, u)
+    ref = torch.tanh(F.conv2d(F.relu(h * scale[None, :, None, None] + shift[None, :, None, None]), Wsn, bias, 1, 1))
+    go = torch.randn_like(ref)
+    gref = torch.autograd.grad((ref * go).sum(), [h, scale, shift, W, bias])
+    rec, Wv, _, _ = make_rec(W.detach(), u, torch.ones(1, device=dev), kind=ops.KIND_C1_OUT)
+    ha = nhwc(h.detach()).requires_grad_(True)
+    sc2, sh2 = scale.detach().clone().requires_grad_(True), shift.detach().clone().requires_grad_(True)
+    Wp, b2 = Wv.detach().requires_grad_(True), bias.detach().clone().requires_grad_(True)
+    y = ops.OutputConvFn.apply(ha, sc2, sh2, Wp, b2, rec)
+    close(y, ref, 2e-3, "output conv")
+    g = torch.autograd.grad((y * go).sum(), [ha, sc2, sh2, Wp, b2])
+    for n, a, b in zip(("h", "scale", "shift", "W", "bias"), g, gref):
+        close(nchw(a) if n == "h" else a, b, 2e-2, f"output conv grad {n}")
+
+
+def test_bn_finalize_matches_batch_norm(dev):
+    """stats -> scale/shift equals F.batch_norm * (1+gain) + bias, with the running-stat update and
+    the complete backward (through mean / var) folded into (dsum, dsumsq)."""
+    import ops
+    torch.manual_seed(5)
+    N, C, Hh, Ww = 4, 32, 6, 10
+    x = r16(torch.randn(N, C, Hh, Ww, device=dev) * 1.5 + 0.3).requires_grad_(True)
+    gb = (0.3 * torch.randn(N, 2 * C, device=dev)).requires_grad_(True)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    ref = F.batch_norm(x, rm.clone(), rv.clone(), None, None, True, 0.1, 1e-5) * (1 + gb[:, :C, None, None]) + gb[:, C:, None, None]
+    ref = F.relu(ref)
+    go = torch.randn_like(ref)
+    gref = torch.autograd.grad((ref * go).sum(), [x, gb])
+    rm_ref, rv_ref = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    F.batch_norm(x.detach(), rm_ref, rv_ref, None, None, True, 0.1, 1e-5)
+    # HIP: stats from the layout kernel, finalize, apply through the conv prologue (identity weights)
+    import layers
+    x2 = x.detach().clone().requires_grad_(True)
+    gb2 = gb.detach().clone().requires_grad_(True)
+    xa, st = ops.ToNHWCFn.apply(x2, True)
+    bank = ops.GainBank(gb2, 1)
+    s, t = ops.BNFinalizeFn.apply(st, gb2, bank, 0, C, C, rm, rv, N * Hh * Ww, 1e-5, 0.1, True)
+    out = layers._affine_act(xa, s, t, relu=True)
+    close(nchw(out), ref, 1.5e-2, "bn+relu out")
+    close(rm, rm_ref, 1e-3, "running mean")
+    close(rv, rv_ref, 1e-3, "running var")
+    g = torch.autograd.grad((out.float() * nhwc(go).float()).sum(), [x2, gb2])
+    close(g[0], gref[0], 3e-2, "bn dx")
+    close(g[1], gref[1], 3e-2, "bn dgain/dbias")
+
+
+def test_diffaug_and_cr(dev, golden_dir):
+    import cr_diff_aug
+    import diff_aug
+    g = np.load(os.path.join(golden_dir, "op_diffaug.npz"))
+    x = torch.from_numpy(g["x"]).to(dev).requires_grad_(True)
+    draws = {k[2:]: torch.from_numpy(g[k]).to(dev) for k in g.files if k.startswith("d_")}
+    y = diff_aug.DiffAugment(x, "color,translation,cutout", draws=draws)
+    close(y, torch.from_numpy(g["y"]), 1e-5, "diffaug fwd (golden)")
+    (gx,) = torch.autograd.grad(y, [x], torch.from_numpy(g["go"]).to(dev))
+    close(gx, torch.from_numpy(g["gx"]), 1e-5, "diffaug bwd (golden)")
+    for seed in (7, 8):
+        g = np.load(os.path.join(golden_dir, f"op_crdiffaug_{seed}.npz"))
+        draws = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("d_")}
+        y = cr_diff_aug.CR_DiffAug(torch.from_numpy(g["x"]).to(dev), draws=draws)
+        assert torch.equal(y.cpu(), torch.from_numpy(g["y"])), "cr_diffaug (golden)"
+
+
+def test_adam_and_ema(dev, golden_dir):
+    import _hip
+    a = np.load(os.path.join(golden_dir, "op_adam.npz"))
+    w = torch.from_numpy(a["w0"]).to(dev)
+    m, v = torch.zeros_like(w), torch.zeros_like(w)
+    for step in range(1, 4):
+        gr = torch.from_numpy(a["grads"][step - 1]).to(dev)
+        _hip.call("ieagan_adam_step", w.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), w.numel(), 5e-5, 0.0, 0.999,
+                  1e-6, step, 1.0, _hip.stream())
+    close(w, torch.from_numpy(a["w3"]), 1e-6, "adam (golden)")
+    t, s = torch.randn(1000, device=dev), torch.randn(1000, device=dev)
+    exp = t * 0.9 + s * 0.1
+    _hip.call("ieagan_ema_update", t.data_ptr(), s.data_ptr(), 1000, 0.9, _hip.stream())
+    close(t, exp, 1e-6, "ema")
