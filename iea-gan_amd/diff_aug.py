@@ -14,6 +14,7 @@ import _hip as H
 import ops
 
 FULL_POLICY = "color,translation,cutout"
+NEXT_DRAWS = []      # FIFO of explicit draw dicts consumed by the next DiffAugment calls (tests)
 
 
 def draw(n, h, w, device, generator=None):
@@ -37,6 +38,8 @@ def DiffAugment(x, policy="", channels_first=True, draws=None):
                                   "(what model.G_D applies, reference model.py:971-978)")
     H.require_gpu()
     n, _, h, w = x.shape
+    if draws is None and NEXT_DRAWS:
+        draws = NEXT_DRAWS.pop(0)                          # explicit draws injected by a parity test
     d = draws if draws is not None else draw(n, h, w, x.device)
     f = lambda t: t.reshape(n).to(device=x.device, dtype=torch.float32).contiguous()
     g = lambda t: t.reshape(n).to(device=x.device, dtype=torch.int64).contiguous()

@@ -222,6 +222,8 @@ class Generator(nn.Module):
         recs = plan["bank"].run(self.training, self.SN_eps)
         N = y.size(0)
         ye = self.shared(y)
+        if rdof is None:
+            rdof = self.__dict__.pop("_next_rdof", None)    # explicit draw injected by a parity test
         if rdof is None:   # the reference draws a fixed 40 rows here (model.py:466); we follow the batch
             rdof = torch.randn(N, self.rdof_dim, device=z.device)
         ye = self.linear_f.fused(torch.cat([ye, rdof], 1), recs["linear_f"])

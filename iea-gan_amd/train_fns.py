@@ -58,7 +58,20 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
         else:
             then()
 
-    def train(x, y):
+    def train(x, y, noise=None):
+        """``noise`` (optional, parity tests): {'z_d','rdof_d','aug_d','z_g','rdof_g','aug_g'} replaces the
+        draws of the two generator passes; None = sample exactly where the reference samples."""
+        import diff_aug as _da
+
+        def sample(phase):
+            if noise is None:
+                z_.sample_()
+                return
+            z_.copy_(noise["z_" + phase].to(z_.device))
+            G.__dict__["_next_rdof"] = noise["rdof_" + phase].to(z_.device)
+            if config["diff_aug"]:
+                _da.NEXT_DRAWS.append(noise["aug_" + phase])
+
         G.optim.zero_grad()
         D.optim.zero_grad()
         x_aug = CR_DiffAug(x) if config["Con_reg"] else None
@@ -78,7 +91,7 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
         for _ in range(config["num_D_steps"]):
             D.optim.zero_grad()
             for _ in range(config["num_D_accumulations"]):
-                z_.sample_()
+                sample("d")
                 joint_aug = config["Con_reg"] and not config["split_D"]
                 outs = GD(z_[:bs], ys[counter], xs[counter], ys[counter], xa[counter] if joint_aug else None, contra=contra,
                           train_G=False, split_D=config["split_D"], diff_aug=config["diff_aug"])
@@ -125,7 +138,7 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
 
         # ------------------------------------------------------------------ G phase
         for _ in range(config["num_G_accumulations"]):
-            z_.sample_()
+            sample("g")
             if contra:
                 cls_proxies_fake, cls_embed_fake, D_fake = GD(z_, ys[counter], x_aug=None, contra=True, train_G=True,
                                                              split_D=config["split_D"], diff_aug=config["diff_aug"])

@@ -1,0 +1,132 @@
+"""Shared parity harness: HIP path (product modules on cuda) against the CPU oracle on identical
+synthetic weights / noise.  Test infrastructure (imports oracle/); used by tests/ and smoke()."""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "iea-gan_amd"), os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import ieagan_oracle as O  # noqa: E402
+
+
+def make_cfg(**over):
+    from defaults import default_config
+    cfg = default_config()
+    cfg.update(device="cuda", ema=False)
+    cfg.update(over)
+    return cfg
+
+
+def build_product(cfg, g_state, d_state, device):
+    import model
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        G = model.Generator(**dict(cfg, skip_init=True)).to(device)
+        D = model.Discriminator(**dict(cfg, skip_init=True)).to(device)
+    G.load_state_dict(g_state)
+    D.load_state_dict(d_state)
+    G.train()
+    D.train()
+    return G, D
+
+
+def make_noise(n, res_h, res_w, seed, rdof_dim=4, dim_z=128):
+    gen = torch.Generator().manual_seed(seed)
+    noise = {}
+    for ph in "dg":
+        noise["z_" + ph] = torch.randn(n, dim_z, generator=gen)
+        noise["rdof_" + ph] = torch.randn(n, rdof_dim, generator=gen)
+        noise["aug_" + ph] = O.diffaug_draws(n, res_h, res_w, generator=gen)
+    return noise
+
+
+def rel_l2(a, b):
+    a, b = a.detach().float().cpu().reshape(-1), b.detach().float().cpu().reshape(-1)
+    return float((a - b).norm() / b.norm().clamp_min(1e-12))
+
+
+def cosine(a, b):
+    a, b = a.detach().float().cpu().reshape(-1), b.detach().float().cpu().reshape(-1)
+    return float(torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-20))
+
+
+def forward_parity(resolution=64, H_base=1, device="cuda:0", n=40, seed=5):
+    """G(z,y) then D(G_z, y) in training mode: outputs + updated buffers vs the oracle."""
+    cfg = make_cfg(resolution=resolution, H_base=H_base, n_classes=max(n, 40))
+    g_state, d_state = O.synth_nets(cfg, 101, 202)
+    G, D = build_product(cfg, g_state, d_state, device)
+    gen = torch.Generator().manual_seed(seed)
+    z, rdof, y = torch.randn(n, 128, generator=gen), torch.randn(n, 4, generator=gen), torch.arange(n)
+    with torch.no_grad():
+        gz = G(z.to(device), y.to(device), rdof=rdof.to(device))
+        pr, em, do = D(gz, y.to(device))
+        torch.cuda.synchronize()
+        gsd = {k: v.clone() for k, v in g_state.items()}
+        dsd = {k: v.clone() for k, v in d_state.items()}
+        t0 = time.time()
+        gz_o = O.generator(gsd, cfg, z, y, rdof, True)
+        pr_o, em_o, do_o = O.discriminator(dsd, cfg, gz.float().cpu(), y, True)
+        t_cpu = time.time() - t0
+    rep = {"G_rel_l2": rel_l2(gz, gz_o), "G_maxabs": float((gz.cpu() - gz_o).abs().max()),
+           "D_out_rel_l2": rel_l2(do, do_o), "D_embed_rel_l2": rel_l2(em, em_o), "D_proxy_rel_l2": rel_l2(pr, pr_o),
+           "G_u_linear": rel_l2(G.state_dict()["linear.u0"], gsd["linear.u0"]),
+           "G_bn_mean": rel_l2(G.state_dict()["blocks.0.0.bn1.stored_mean"], gsd["blocks.0.0.bn1.stored_mean"]),
+           "G_bn_var_last": rel_l2(G.state_dict()["output_layer.0.stored_var"], gsd["output_layer.0.stored_var"]),
+           "D_u_conv": rel_l2(D.state_dict()["blocks.0.0.conv2.u0"], dsd["blocks.0.0.conv2.u0"]), "oracle_s": t_cpu}
+    return rep, (G, D, gz, gz_o)
+
+
+# stated bf16 tolerances (CPU bf16-autocast of the reference itself gives G 3.0e-2,
+# D logits 1.6e-2, embeddings 9e-3 rel-L2 at this geometry)
+TOL = {"G_rel_l2": 5e-2, "D_out_rel_l2": 5e-2, "D_embed_rel_l2": 3e-2, "D_proxy_rel_l2": 1e-4, "loss": 5e-2,
+       "grad_cos": 0.97}
+
+
+def step_parity(resolution=64, H_base=1, device="cuda:0", verbose=False, **cfg_over):
+    """One full train(x, y) (finite clip_norm so that G steps) on the HIP path vs the oracle:
+    the 5 losses, and the cosine between the flat G / D gradients."""
+    import model
+    import train_fns
+    import utils
+    cfg = make_cfg(resolution=resolution, H_base=H_base, clip_norm=1e9, **cfg_over)
+    n, hh, ww = 40, resolution, resolution * H_base
+    g_state, d_state = O.synth_nets(cfg, 101, 202)
+    G, D = build_product(cfg, g_state, d_state, device)
+    GD = model.G_D(G, D)
+    z_, y_ = utils.prepare_z_y(n, G.dim_z, cfg["n_classes"], device=device)
+    train = train_fns.GAN_training_function(G, D, GD, z_, y_, None, {"itr": 1}, cfg, device)
+    x = O.synth_event(n, hh, ww, 303)
+    y = torch.arange(n)
+    noise = make_noise(n, hh, ww, 909)
+    out = train(x.to(device), y.to(device), noise=noise)
+    torch.cuda.synchronize()
+    g_grad = G._arena.grad.clone().cpu()
+    d_grad = D._arena.grad.clone().cpu()
+    # oracle
+    gsd, gp = O.as_trainable(g_state)
+    dsd, dp = O.as_trainable(d_state)
+    ts = O.TrainState(gsd, dsd, gp, dp, cfg)
+    ref = O.train_step(ts, x, y, noise, itr=1)
+    og, od = ts.last_grads
+
+    def flat(net, grads):
+        ar = net._arena
+        f = torch.zeros(ar.n_param)
+        names = [k for k, _ in net.named_parameters()]
+        for (p, o, cnt), k in zip(ar.param_slices, names):
+            f[o:o + cnt] = grads[k].reshape(-1)
+        return f
+    og_f, od_f = flat(G, og), flat(D, od)
+    rep = {"losses": out, "ref_losses": ref, "G_grad_cos": cosine(g_grad, og_f), "D_grad_cos": cosine(d_grad, od_f),
+           "G_grad_rel": rel_l2(g_grad, og_f), "D_grad_rel": rel_l2(d_grad, od_f)}
+    ok = all(abs(out[k] - ref[k]) <= TOL["loss"] * max(1.0, abs(ref[k])) for k in ref)
+    ok = ok and rep["G_grad_cos"] >= TOL["grad_cos"] and rep["D_grad_cos"] >= TOL["grad_cos"]
+    rep["ok"] = bool(ok)
+    if verbose:
+        print(rep)
+    return rep
