@@ -15,15 +15,20 @@
 // block-level reduction of 8 per-thread partials by channel group; thread t owns channel group
 // (t % groups); result is added into dst[replica][c] with float atomics.
 // ------------------------------------------------------------------------------------------------
+// Only the first `active` = (256 / groups) * groups threads of a block carry data, so that a thread's
+// channel group stays fixed over a grid-stride loop for ANY channel count that is a multiple of 8.
+__device__ __forceinline__ int active_threads(int groups) { return (256 / groups) * groups; }
+
 __device__ __forceinline__ void reduce_groups_atomic(float (&part)[8], int groups, float* dst, float* red /*[256][8]*/) {
     const int t = threadIdx.x;
+    const int active = active_threads(groups);
 #pragma unroll
     for (int i = 0; i < 8; ++i) red[t * 8 + i] = part[i];
     __syncthreads();
     for (int o = t; o < groups * 8; o += 256) {
         const int g = o >> 3, i = o & 7;
         float s = 0.f;
-        for (int u = g; u < 256; u += groups) s += red[u * 8 + i];
+        for (int u = g; u < active; u += groups) s += red[u * 8 + i];
         atomicAdd(dst + g * 8 + i, s);
     }
     __syncthreads();
@@ -46,7 +51,8 @@ __global__ __launch_bounds__(256) void effgrad_kernel(const bf16* __restrict__ d
         dq[i] = dstat ? 2.f * dstat[C + cg * 8 + i] : 0.f;
         part[i] = 0.f;
     }
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < chunks; idx += (long)gridDim.x * 256) {
+    const int act = active_threads(groups);
+    for (long idx = (long)blockIdx.x * act + threadIdx.x; idx < chunks && threadIdx.x < act; idx += (long)gridDim.x * act) {
         const bf16x8 d = *(const bf16x8*)(dout + idx * 8);
         float v[8];
 #pragma unroll
@@ -69,7 +75,7 @@ __global__ __launch_bounds__(256) void effgrad_kernel(const bf16* __restrict__ d
 
 extern "C" int ieagan_effgrad(const void* dout, const void* out, const float* dstat, void* geff, float* colsum,
                               long P, int C, void* stream) {
-    CHECK_ARG(C % 8 == 0 && 256 % (C / 8) == 0, "effgrad: C=%d must be 8*2^k <= 2048", C);
+    CHECK_ARG(C % 8 == 0 && C <= 2048, "effgrad: C=%d must be a multiple of 8, <= 2048", C);
     CHECK_ARG(dstat == nullptr || (out != nullptr && geff != nullptr), "effgrad: dstat needs out and geff");
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof("effgrad", 0.0, (dstat ? 6.0 : 2.0) * P * C, st);
@@ -107,7 +113,8 @@ __global__ __launch_bounds__(256) void prologue_bwd_kernel(const bf16* __restric
         p_ds[i] = p_dt[i] = 0.f;
     }
     const long chunks = (long)Hs * Ws * groups;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < chunks; idx += (long)gridDim.x * 256) {
+    const int act = active_threads(groups);
+    for (long idx = (long)blockIdx.x * act + threadIdx.x; idx < chunks && threadIdx.x < act; idx += (long)gridDim.x * act) {
         const long sp = idx / groups;        // source pixel within the image (idx % groups == cg)
         const int hs = (int)(sp / Ws), ws = (int)(sp - (long)hs * Ws);
         float d[8];
@@ -152,7 +159,7 @@ __global__ __launch_bounds__(256) void prologue_bwd_kernel(const bf16* __restric
 extern "C" int ieagan_prologue_bwd(const void* da, const void* x, int Cx, const float* scale, const float* shift,
                                    int nstride, int relu, int rs, void* dx, float* dscale, float* dshift, int N, int Hs,
                                    int Ws, int C, void* stream) {
-    CHECK_ARG(C % 8 == 0 && 256 % (C / 8) == 0, "prologue_bwd: C=%d unsupported", C);
+    CHECK_ARG(C % 8 == 0 && C <= 2048, "prologue_bwd: C=%d unsupported", C);
     CHECK_ARG(rs >= 0 && rs <= 2, "prologue_bwd: bad rs");
     CHECK_ARG(rs != 2 || (Hs % 2 == 0 && Ws % 2 == 0), "prologue_bwd: pooled source needs even size");
     CHECK_ARG(scale == nullptr || (shift && dscale && dshift), "prologue_bwd: affine needs shift/dscale/dshift");
@@ -406,7 +413,8 @@ __global__ __launch_bounds__(256) void stats_kernel(const bf16* __restrict__ x, 
 #pragma unroll
     for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
     const long chunks = P * groups;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < chunks; idx += (long)gridDim.x * 256) {
+    const int act = active_threads(groups);
+    for (long idx = (long)blockIdx.x * act + threadIdx.x; idx < chunks && threadIdx.x < act; idx += (long)gridDim.x * act) {
         const bf16x8 v = *(const bf16x8*)(x + idx * 8);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -421,7 +429,7 @@ __global__ __launch_bounds__(256) void stats_kernel(const bf16* __restrict__ x, 
 }
 
 extern "C" int ieagan_channel_stats(const void* x, float* stats, long P, int C, void* stream) {
-    CHECK_ARG(C % 8 == 0 && 256 % (C / 8) == 0, "channel_stats: C=%d unsupported", C);
+    CHECK_ARG(C % 8 == 0 && C <= 2048, "channel_stats: C=%d unsupported", C);
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof("channel_stats", 0.0, 2.0 * P * C, st);
     long blocks = (P * (C / 8) + 255) / 256;
