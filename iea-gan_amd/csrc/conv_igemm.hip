@@ -101,7 +101,8 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(ConvArgs a) {
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int ksteps = a.Kpad >> 5;
-    const bf16* wrow = (const bf16*)a.w + (long)(n_base + lr) * a.Kpad + lg * 8;
+    const bool col_ok = (n_base + (NT - 1) * 16 + lr) < a.Cout;     // only NT == 1 can have a half-empty n-tile
+    const bf16* wrow = (const bf16*)a.w + (long)(col_ok ? n_base + lr : 0) * a.Kpad + lg * 8;
     for (int ks = 0; ks < ksteps; ++ks) {
         const int k = ks * 32 + lg * 8;
         int tap = 0, c = k;
@@ -114,7 +115,10 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(ConvArgs a) {
         const int dx = (TAPS == 9) ? (tap - (tap / 3) * 3 - 1) : 0;
         bf16x8 bfrag[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bfrag[nt] = *(const bf16x8*)(wrow + (long)nt * 16 * a.Kpad + ks * 32);
+        for (int nt = 0; nt < NT; ++nt) {
+            bfrag[nt] = *(const bf16x8*)(wrow + (long)nt * 16 * a.Kpad + ks * 32);
+            if (NT == 1 && !col_ok) bfrag[nt] = zero8();
+        }
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const bf16x8 af = gather8<AFF, RELU, RS>(a.src, H, W, pn[mt], ph[mt] + dy, pw[mt] + dx, c, pv[mt] && kval);
@@ -144,6 +148,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(ConvArgs a) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int co = n_base + nt * 16 + lr;
+                if (NT == 1 && !col_ok) continue;
                 float v = acc[mt][nt][r];
                 if (a.bias) v += a.bias[co];
                 if (a.ra != nullptr && co < a.Ca) {
@@ -181,7 +186,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(ConvArgs a) {
             }
         }
         __syncthreads();
-        if (threadIdx.x < NT * 16) {
+        if (threadIdx.x < NT * 16 && n_base + (int)threadIdx.x < a.Cout) {
             const int t = threadIdx.x;
             const float x1 = red[0][t][0] + red[1][t][0] + red[2][t][0] + red[3][t][0];
             const float x2 = red[0][t][1] + red[1][t][1] + red[2][t][1] + red[3][t][1];
@@ -201,7 +206,7 @@ static int launch_gather_nt(const ConvArgs& a, hipStream_t st) {
     } else if (a.Cout % 32 == 0) {
         hipLaunchKernelGGL((conv_gather_kernel<TAPS, AFF, RELU, RS, 2>), dim3(gx, a.Cout / 32), dim3(256), 0, st, a);
     } else {
-        hipLaunchKernelGGL((conv_gather_kernel<TAPS, AFF, RELU, RS, 1>), dim3(gx, a.Cout / 16), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((conv_gather_kernel<TAPS, AFF, RELU, RS, 1>), dim3(gx, (a.Cout + 15) / 16), dim3(256), 0, st, a);
     }
     return 0;
 }
@@ -217,7 +222,7 @@ static int launch_gather_pro(const ConvArgs& a, hipStream_t st) {
 
 int conv_gather_launch(const ConvArgs& a, hipStream_t st) {
     CHECK_ARG(a.taps == 1 || a.taps == 9, "conv: taps must be 1 or 9 (got %d)", a.taps);
-    CHECK_ARG(a.Cin % 16 == 0 && a.Cout % 16 == 0, "conv: Cin/Cout must be multiples of 16 (%d,%d)", a.Cin, a.Cout);
+    CHECK_ARG(a.Cin % 8 == 0 && a.Cout % 8 == 0, "conv: Cin/Cout must be multiples of 8 (%d,%d)", a.Cin, a.Cout);
     CHECK_ARG(a.Kpad % 32 == 0 && a.Kpad >= a.taps * a.Cin, "conv: bad Kpad %d", a.Kpad);
     CHECK_ARG(a.src.rs >= 0 && a.src.rs <= 2, "conv: bad resample mode %d", a.src.rs);
     CHECK_ARG(a.src.Cx % 8 == 0, "conv: source channel stride must be a multiple of 8");
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             const int px = idx / (GC / 8), cc = idx - px * (GC / 8);
             const int hh = h0 + px / WG_TW, ww = w0 + px % WG_TW;
             bf16x8 v = zero8();
-            if (hh < H && ww < W) v = *(const bf16x8*)((const bf16*)a.g + (((long)n * H + hh) * W + ww) * a.Cg + cout0 + cc * 8);
+            if (hh < H && ww < W && cout0 + cc * 8 < a.Cout) v = *(const bf16x8*)((const bf16*)a.g + (((long)n * H + hh) * W + ww) * a.Cg + cout0 + cc * 8);
             *(bf16x8*)(lds_g + px * GC + cc * 8) = v;
         }
         // ---- stage a tile (+halo) with the fused prologue
@@ -357,7 +362,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                atomicAdd(a.dw + (long)(cout0 + mt * 16 + lg * 4 + r) * a.Kpad + t_kcol[j] + lr, acc[mt][j][r]);
+                if (cout0 + mt * 16 + lg * 4 + r < a.Cout)
+                    atomicAdd(a.dw + (long)(cout0 + mt * 16 + lg * 4 + r) * a.Kpad + t_kcol[j] + lr, acc[mt][j][r]);
     }
 }
 
@@ -383,7 +389,7 @@ static void launch_wgrad_pro(const WgradArgs& a, hipStream_t st, int mt, dim3 gr
 int conv_wgrad_launch(const WgradArgs& a0, hipStream_t st, int use_tr) {
     WgradArgs a = a0;
     CHECK_ARG(a.taps == 1 || a.taps == 9, "wgrad: taps must be 1 or 9");
-    CHECK_ARG(a.Cin % 16 == 0 && a.Cout % 16 == 0, "wgrad: Cin/Cout must be multiples of 16 (%d,%d)", a.Cin, a.Cout);
+    CHECK_ARG(a.Cin % 16 == 0 && a.Cout % 8 == 0, "wgrad: Cin %% 16 and Cout %% 8 required (%d,%d)", a.Cin, a.Cout);
     CHECK_ARG(a.Kpad >= a.taps * a.Cin, "wgrad: bad Kpad");
     CHECK_ARG(a.Cg >= a.Cout && a.Cg % 8 == 0, "wgrad: bad g channel stride %d", a.Cg);
     if (a.src.rs == 1) CHECK_ARG(a.H == 2 * a.src.Hs && a.W == 2 * a.src.Ws, "wgrad: upsample geometry mismatch");
@@ -392,7 +398,7 @@ int conv_wgrad_launch(const WgradArgs& a0, hipStream_t st, int use_tr) {
     // cout chunking: MT m-tiles per block (<= 8)
     int mt = 8;
     if (a.Cout % 128 != 0) mt = (a.Cout % 64 == 0) ? 4 : (a.Cout % 32 == 0) ? 2 : 1;
-    const int gz = a.Cout / (mt * 16);
+    const int gz = (a.Cout + mt * 16 - 1) / (mt * 16);
     const int nt_total = a.taps * (a.Cin / 16);
     const int gy = (nt_total + 15) / 16;
     const long tiles = (long)a.N * ((a.H + WG_TH - 1) / WG_TH) * ((a.W + WG_TW - 1) / WG_TW);

@@ -1,7 +1,7 @@
 // Batched spectral normalisation (one power iteration, one singular value) for ALL spectrally
 // normalised layers of a network in three launches, instead of ~5 tiny ATen ops per layer
 // (the reference issues 147 (G) + 64 (D) power iterations per forward: layers.py:89-111, 151-165):
-//   phase 1: v_raw = u W                       (atomic column sums per row chunk)
+//   phase 1: v_raw = u W                       (per-row-chunk partial column sums, folded in order)
 //   phase 2: t = W v,  v = v_raw / max(|v_raw|, eps);  tt += t^2
 //   phase 3: sigma = tt / max(sqrt(tt), eps), u' = t / max(sqrt(tt), eps);  u <- u' and sv <- sigma when
 //            training;  write the normalised weight W / sigma in the layout its consumer wants
@@ -12,14 +12,14 @@
 #include "common.h"
 
 #define SN_FIELDS 16
-enum { F_W = 0, F_U, F_SV, F_OUT, F_IN, F_TAPS, F_CIN, F_KIND, F_CTX, F_PACK, F_PACK2, F_KPAD, F_KPAD2 };
+enum { F_W = 0, F_U, F_SV, F_OUT, F_IN, F_TAPS, F_CIN, F_KIND, F_CTX, F_PACK, F_PACK2, F_KPAD, F_KPAD2, F_PART };
 // kinds: 0 fp32 [out][in] copy (linear / embedding)
 //        1 conv pack: bf16 fwd [out][kpad] (k = tap*cin + c) at F_PACK and bf16 dgrad [cin][kpad2]
 //          (k' = (taps-1-tap)*out + o) at F_PACK2 (byte offsets)
 //        2 single-channel INPUT conv (weight [C][1][3][3]) -> fp32 [9][C] at F_PACK
 //        3 single-channel OUTPUT conv (weight [1][C][3][3]) -> fp32 [9][C] at F_PACK
-// ctx layout per layer (fp32, at F_CTX): [0] sigma, [1] tt, [2] |v_raw|^2 (unused), [8 .. 8+out) u',
-//   [8+out .. 8+out+in) v_raw, [8+out+in .. 8+out+2*in) v
+// ctx layout per layer (fp32, at F_CTX): [0] sigma, [8 .. 8+out) u', [8+out .. 8+out+in) v_raw,
+//   [8+out+in .. 8+out+2*in) v, [8+out+2*in .. 8+2*out+2*in) t = W v
 #define SN_ROWS 32
 
 __device__ __forceinline__ float block_sum(float v, float* red) {
@@ -33,20 +33,36 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return s;
 }
 
+// All reductions are ordered (per-chunk partial sums folded in a fixed order, no float atomics), so the
+// normalised weights -- and with them every replica in a data-parallel run -- are bit-reproducible.
 __global__ __launch_bounds__(256) void sn_phase1_kernel(const long* __restrict__ tab, const int* __restrict__ blocks,
-                                                        const float* __restrict__ params, float* __restrict__ ctx) {
+                                                        const float* __restrict__ params, float* __restrict__ part) {
     const long* L = tab + (long)blocks[2 * blockIdx.x] * SN_FIELDS;
     const int row0 = blocks[2 * blockIdx.x + 1];
     const int out = (int)L[F_OUT], in = (int)L[F_IN];
     const float* W = params + L[F_W];
     const float* u = params + L[F_U];
-    float* vraw = ctx + L[F_CTX] + 8 + out;
+    float* dst = part + L[F_PART] + (long)(row0 / SN_ROWS) * in;
     const int r1 = min(row0 + SN_ROWS, out);
     for (int i = threadIdx.x; i < in; i += 256) {
         float s = 0.f;
         for (int o = row0; o < r1; ++o) s += u[o] * W[(long)o * in + i];
-        atomicAdd(vraw + i, s);
+        dst[i] = s;
     }
+}
+
+// fold the row-chunk partials: one block per (layer, 256-column tile)
+__global__ __launch_bounds__(256) void sn_phase1b_kernel(const long* __restrict__ tab, const int* __restrict__ cblocks,
+                                                         const float* __restrict__ part, float* __restrict__ ctx) {
+    const long* L = tab + (long)cblocks[2 * blockIdx.x] * SN_FIELDS;
+    const int i = cblocks[2 * blockIdx.x + 1] + threadIdx.x;
+    const int out = (int)L[F_OUT], in = (int)L[F_IN];
+    if (i >= in) return;
+    const int chunks = (out + SN_ROWS - 1) / SN_ROWS;
+    const float* src = part + L[F_PART] + i;
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += src[(long)c * in];
+    ctx[L[F_CTX] + 8 + out + i] = s;
 }
 
 __global__ __launch_bounds__(256) void sn_phase2_kernel(const long* __restrict__ tab, const int* __restrict__ blocks,
@@ -67,17 +83,12 @@ __global__ __launch_bounds__(256) void sn_phase2_kernel(const long* __restrict__
         for (int i = threadIdx.x; i < in; i += 256) v[i] = vraw[i] * inv;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r1 = min(row0 + SN_ROWS, out);
-    float tt = 0.f;
     for (int o = row0 + wave; o < r1; o += 4) {
         float s = 0.f;
         for (int i = lane; i < in; i += 64) s += W[(long)o * in + i] * (vraw[i] * inv);
         s = wave_sum(s);
-        if (lane == 0) {
-            c[8 + o] = s;
-            tt += s * s;
-        }
+        if (lane == 0) c[8 + out + 2 * in + o] = s;            // t[o]; phase 3 turns it into u'
     }
-    if (lane == 0 && tt != 0.f) atomicAdd(c + 1, tt);
 }
 
 __global__ __launch_bounds__(256) void sn_phase3_kernel(const long* __restrict__ tab, const int* __restrict__ blocks,
@@ -89,15 +100,17 @@ __global__ __launch_bounds__(256) void sn_phase3_kernel(const long* __restrict__
     const int kpad = (int)L[F_KPAD], kpad2 = (int)L[F_KPAD2];
     const float* W = params + L[F_W];
     float* c = ctx + L[F_CTX];
-    const float tt = c[1];
+    __shared__ float red3[4];
+    const float* tvec = c + 8 + out + 2 * in;
+    float tt = 0.f;
+    for (int o = threadIdx.x; o < out; o += 256) tt += tvec[o] * tvec[o];     // same order in every block
+    tt = block_sum(tt, red3);
     const float un = fmaxf(sqrtf(tt), eps);
     const float sigma = tt / un;
     const float isg = 1.f / sigma;
     const int r1 = min(row0 + SN_ROWS, out);
-    // every block of the layer rescales its own rows of t into u'; no block reads another's rows
-    __syncthreads();
     for (int o = row0 + threadIdx.x; o < r1; o += 256) {
-        const float un_o = c[8 + o] / un;
+        const float un_o = tvec[o] / un;
         c[8 + o] = un_o;
         if (training) params[L[F_U] + o] = un_o;
     }
@@ -142,12 +155,13 @@ __global__ __launch_bounds__(256) void sn_phase3_kernel(const long* __restrict__
     }
 }
 
-extern "C" int ieagan_sn_forward(const long* tab, const int* blocks, int nblocks, float* params, float* ctx, void* pack,
-                                 float eps, int training, void* stream) {
+extern "C" int ieagan_sn_forward(const long* tab, const int* blocks, int nblocks, const int* cblocks, int ncblocks,
+                                 float* params, float* ctx, float* part, void* pack, float eps, int training, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (nblocks <= 0) return 0;
     ProfScope prof("sn_forward", 0.0, 0.0, st);
-    hipLaunchKernelGGL(sn_phase1_kernel, dim3(nblocks), dim3(256), 0, st, tab, blocks, (const float*)params, ctx);
+    hipLaunchKernelGGL(sn_phase1_kernel, dim3(nblocks), dim3(256), 0, st, tab, blocks, (const float*)params, part);
+    hipLaunchKernelGGL(sn_phase1b_kernel, dim3(ncblocks), dim3(256), 0, st, tab, cblocks, (const float*)part, ctx);
     hipLaunchKernelGGL(sn_phase2_kernel, dim3(nblocks), dim3(256), 0, st, tab, blocks, (const float*)params, ctx, eps);
     hipLaunchKernelGGL(sn_phase3_kernel, dim3(nblocks), dim3(256), 0, st, tab, blocks, params, ctx, (char*)pack, eps, training);
     CHECK_LAUNCH("sn_forward");

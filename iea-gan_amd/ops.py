@@ -56,8 +56,8 @@ class SNBank:
         self.names = [e[0] for e in entries]
         self.index = {n: i for i, n in enumerate(self.names)}
         dev = arena.device
-        rows, blocks = [], []
-        ctx_off, pack_off = 0, 0
+        rows, blocks, cblocks = [], [], []
+        ctx_off, pack_off, part_off = 0, 0, 0
         self.meta = []
         base = arena.data_ptr()
 
@@ -96,28 +96,35 @@ class SNBank:
         for i, (n, kind, w, u, sv) in enumerate(entries):
             p1, p2, kpad, kpad2, taps, cin, out, inn = place[n]
             row = [0] * H.SN_FIELDS
-            row[0:13] = [off(w), off(u), off(sv), out, inn, taps, cin, kind, ctx_off, p1, p2, kpad, kpad2]
+            row[0:14] = [off(w), off(u), off(sv), out, inn, taps, cin, kind, ctx_off, p1, p2, kpad, kpad2, part_off]
             rows.append(row)
             self.meta.append((kind, out, inn, taps, cin, kpad, kpad2, ctx_off, p1, p2))
-            ctx_off += (8 + out + 2 * inn + 7) // 8 * 8
+            ctx_off += (8 + 2 * out + 2 * inn + 7) // 8 * 8
+            nchunk = (out + self.ROWS - 1) // self.ROWS
+            part_off += nchunk * inn
             for r0 in range(0, out, self.ROWS):
                 blocks.append([i, r0])
-        self.ctx_size, self.pack_size = ctx_off, pack_off
+            for c0 in range(0, inn, 256):
+                cblocks.append([i, c0])
+        self.ctx_size, self.pack_size, self.part_size = ctx_off, pack_off, part_off
         self.table = torch.tensor(rows, dtype=torch.int64, device=dev)
         self.blocks = torch.tensor(blocks, dtype=torch.int32, device=dev)
-        self.nblocks = len(blocks)
+        self.cblocks = torch.tensor(cblocks, dtype=torch.int32, device=dev)
+        self.nblocks, self.ncblocks = len(blocks), len(cblocks)
 
     def run(self, training: bool, eps: float):
         dev = self.arena.device
-        ctx = torch.zeros(self.ctx_size, dtype=torch.float32, device=dev)
+        ctx = torch.empty(self.ctx_size, dtype=torch.float32, device=dev)
+        part = torch.empty(self.part_size, dtype=torch.float32, device=dev)
         pack = torch.empty(self.pack_size, dtype=torch.uint8, device=dev)
-        H.call("ieagan_sn_forward", self.table.data_ptr(), self.blocks.data_ptr(), self.nblocks,
-               self.arena.data_ptr(), ctx.data_ptr(), pack.data_ptr(), float(eps), int(training), H.stream())
+        H.call("ieagan_sn_forward", self.table.data_ptr(), self.blocks.data_ptr(), self.nblocks, self.cblocks.data_ptr(),
+               self.ncblocks, self.arena.data_ptr(), ctx.data_ptr(), part.data_ptr(), pack.data_ptr(), float(eps),
+               int(training), H.stream())
         recs = {}
         for n, (kind, out, inn, taps, cin, kpad, kpad2, coff, p1, p2) in zip(self.names, self.meta):
             r = SNRecord()
             r.kind, r.out, r.inn, r.taps, r.cin, r.kpad, r.kpad2 = kind, out, inn, taps, cin, kpad, kpad2
-            r.ctx = ctx[coff:coff + 8 + out + 2 * inn]
+            r.ctx = ctx[coff:coff + 8 + 2 * out + 2 * inn]
             r.w_fwd = r.w_bwd = r.w_plain = None
             if kind == KIND_CONV:
                 r.w_fwd = pack[p1:p1 + out * kpad * 2].view(BF16).view(out, kpad)

@@ -107,8 +107,8 @@ int ieagan_wgrad_c1(const float* img, const float* tanh_y, const void* t, const 
                     int nstride, int relu, float* dw, int N, int H, int W, int C, int flip, void* stream);
 
 /* ---- batched spectral norm (sn.hip): layers.SN.W_ / power_iteration (layers.py:89-165) -------- */
-int ieagan_sn_forward(const long* table, const int* blocks, int nblocks, float* params, float* ctx, void* pack,
-                      float eps, int training, void* stream);
+int ieagan_sn_forward(const long* table, const int* blocks, int nblocks, const int* cblocks, int ncblocks,
+                      float* params, float* ctx, float* part, void* pack, float eps, int training, void* stream);
 int ieagan_sn_backward(const float* gsn, const float* W, int kind, int out, int in, int taps, int cin, int kpad,
                        const float* ctx, float* inner_scratch, float* dW, void* stream);
 

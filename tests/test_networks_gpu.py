@@ -13,14 +13,13 @@ from parity_util import TOL, forward_parity, rel_l2, step_parity  # noqa: E402
 
 def test_forward_64_vs_oracle_and_golden(golden_dir):
     """40x64x64 (BASELINE configs[0] geometry): G(z,y), D(x,y), SN / BN buffer updates."""
-    rep, (G, D, gz, gz_o) = forward_parity(64, 1)
+    g = np.load(os.path.join(golden_dir, "net_64.npz"))      # same z / rdof as the reference-generated fixture
+    rep, (G, D, gz, gz_o) = forward_parity(64, 1, z=torch.from_numpy(g["z"]), rdof=torch.from_numpy(g["rdof"]))
     print(json.dumps(rep))
     for k in ("G_rel_l2", "D_out_rel_l2", "D_embed_rel_l2", "D_proxy_rel_l2"):
         assert rep[k] <= TOL[k], (k, rep)
     assert rep["G_u_linear"] <= 1e-4 and rep["D_u_conv"] <= 1e-3, rep      # power iteration is fp32
     assert rep["G_bn_mean"] <= 2e-2 and rep["G_bn_var_last"] <= 5e-2, rep
-    # the same inputs as the reference-generated fixture
-    g = np.load(os.path.join(golden_dir, "net_64.npz"))
     assert rel_l2(gz_o, torch.from_numpy(g["gz"])) <= 1e-4        # oracle == reference (sanity)
     assert rel_l2(gz, torch.from_numpy(g["gz"])) <= TOL["G_rel_l2"]
 
