@@ -27,7 +27,7 @@ class SrcDesc(C.Structure):
 class ConvDesc(C.Structure):
     _fields_ = [("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
                 ("taps", C.c_int), ("Kpad", C.c_int), ("src", SrcDesc), ("w", vp), ("bias", vp),
-                ("ra", vp), ("Cra", C.c_int), ("Ca", C.c_int), ("ra_rs", C.c_int), ("rb", vp),
+                ("ra", vp), ("Cra", C.c_int), ("Ca", C.c_int), ("ra_rs", C.c_int), ("ra_scale", C.c_float), ("rb", vp),
                 ("Crb", C.c_int), ("mask", vp), ("out", vp), ("stats", vp)]
 
 
@@ -49,9 +49,10 @@ _SIGS = {
     "ieagan_prof_reset": [],
     "ieagan_prof_collect": [C.POINTER(ProfRec), i],
     "ieagan_conv_forward": [C.POINTER(ConvDesc), vp],
+    "ieagan_conv_force_gather": [i],
     "ieagan_conv_wgrad": [C.POINTER(WgradDesc), i, vp],
     "ieagan_effgrad": [vp, vp, vp, vp, vp, l, i, vp],
-    "ieagan_prologue_bwd": [vp, vp, i, vp, vp, i, i, i, vp, vp, vp, i, i, i, i, vp],
+    "ieagan_prologue_bwd": [vp, vp, i, vp, vp, i, i, i, vp, vp, vp, i, i, i, i, vp, i, i, i, vp],
     "ieagan_bn_finalize_fwd": [vp, f, vp, vp, i, i, f, f, i, vp, vp, vp, vp, vp, i, i, vp],
     "ieagan_bn_finalize_bwd": [vp, vp, vp, i, i, vp, f, i, vp, vp, i, vp, i, i, vp],
     "ieagan_res_bwd": [vp, i, vp, i, i, i, i, i, i, vp],

@@ -98,7 +98,8 @@ template <bool AFF, bool RELU, int RS>
 __global__ __launch_bounds__(256) void prologue_bwd_kernel(const bf16* __restrict__ da, const bf16* __restrict__ x, int Cx,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            int nstride, bf16* __restrict__ dx, float* __restrict__ dscale,
-                                                           float* __restrict__ dshift, int Hs, int Ws, int C) {
+                                                           float* __restrict__ dshift, int Hs, int Ws, int C,
+                                                           const bf16* __restrict__ radd, int Cr, int Ca, int rmode) {
     __shared__ float red[256 * 8];
     const int n = blockIdx.y;
     const int groups = C >> 3;
@@ -146,8 +147,27 @@ __global__ __launch_bounds__(256) void prologue_bwd_kernel(const bf16* __restric
             if (RELU && !(pre > 0.f)) di = 0.f;
             p_ds[i] += di * xf;
             p_dt[i] += di;
-            o[i] = f2bf(AFF ? di * sc[i] : di);
+            d[i] = AFF ? di * sc[i] : di;
         }
+        if (radd != nullptr && cg * 8 < Ca) {
+            // gradient of the shortcut that also read x (the consumer conv's residual operand): added here
+            // so that autograd never has to sum two full-size tensors.  rmode 0: same resolution;
+            // rmode 1: the shortcut was nearest-upsampled -> sum its 2x2 gradients.
+            if (rmode == 0) {
+                const bf16x8 r = *(const bf16x8*)(radd + (((long)n * Hs + hs) * Ws + ws) * Cr + cg * 8);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) d[i] += bf2f(r[i]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bf16x8 r = *(const bf16x8*)(radd + (((long)n * (2 * Hs) + 2 * hs + (q >> 1)) * (2 * Ws) + 2 * ws + (q & 1)) * Cr + cg * 8);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) d[i] += bf2f(r[i]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = f2bf(d[i]);
         *(bf16x8*)(dx + (((long)n * Hs + hs) * Ws + ws) * C + cg * 8) = o;
     }
     if (AFF) {
@@ -158,7 +178,8 @@ __global__ __launch_bounds__(256) void prologue_bwd_kernel(const bf16* __restric
 
 extern "C" int ieagan_prologue_bwd(const void* da, const void* x, int Cx, const float* scale, const float* shift,
                                    int nstride, int relu, int rs, void* dx, float* dscale, float* dshift, int N, int Hs,
-                                   int Ws, int C, void* stream) {
+                                   int Ws, int C, const void* radd, int Cr, int Ca, int rmode, void* stream) {
+    CHECK_ARG(radd == nullptr || (Ca % 8 == 0 && Ca <= C && Ca <= Cr && (rmode == 0 || rmode == 1)), "prologue_bwd: bad shortcut-gradient operand");
     CHECK_ARG(C % 8 == 0 && C <= 2048, "prologue_bwd: C=%d unsupported", C);
     CHECK_ARG(rs >= 0 && rs <= 2, "prologue_bwd: bad rs");
     CHECK_ARG(rs != 2 || (Hs % 2 == 0 && Ws % 2 == 0), "prologue_bwd: pooled source needs even size");
@@ -172,7 +193,7 @@ extern "C" int ieagan_prologue_bwd(const void* da, const void* x, int Cx, const 
     dim3 grid((unsigned)per, N);
     const bool aff = scale != nullptr;
 #define PB(A, R, S) hipLaunchKernelGGL((prologue_bwd_kernel<A, R, S>), grid, dim3(256), 0, st, (const bf16*)da, (const bf16*)x, Cx, \
-                                       scale, shift, nstride, (bf16*)dx, dscale, dshift, Hs, Ws, C)
+                                       scale, shift, nstride, (bf16*)dx, dscale, dshift, Hs, Ws, C, (const bf16*)radd, Cr, Ca, rmode)
 #define PB_RS(A, R)            \
     if (rs == 0) PB(A, R, 0);  \
     else if (rs == 1) PB(A, R, 1); \

@@ -71,10 +71,137 @@ __device__ __forceinline__ bf16x8 gather8(const SrcDesc& s, int H, int W, int n,
 }
 
 // ------------------------------------------------------------------------------------------------
-// conv_gather: block = 4 waves, each wave 2 m-tiles (32 pixels) x NT n-tiles (16*NT channels).
+// Shared epilogue.  The MFMA accumulators of one wave (2 m-tiles x NT n-tiles = 32 pixels x 16*NT
+// channels) are transposed through a wave-private LDS buffer so that every lane then owns 8 consecutive
+// channels of one pixel: bias, ReLU-mask, residual and the output store are all 16-byte accesses, and
+// the per-channel (sum, sumsq) partials stay in registers of a fixed channel group per lane.
+//   pix(row, m, n, h, w) -> bool : pixel of wave-local row (0..31); m = linear NHW index
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+struct EpiLds {
+    static constexpr int LDW = NT * 16 + 4;             // padded row (floats): 4 rows apart -> 16 banks apart
+    static constexpr int FLOATS = 32 * LDW;
+};
+
+template <int NT, typename PixFn>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x4 (&acc)[2][NT], float* wlds, int n_base, PixFn pix,
+                                              float (&s1)[8], float (&s2)[8]) {
+    constexpr int LDW = EpiLds<NT>::LDW;
+    constexpr int CPP = NT * 2;                         // 8-channel chunks per pixel
+    const int lane = threadIdx.x & 63;
+    const int lr = lane & 15, lg = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wlds[(mt * 16 + lg * 4 + r) * LDW + nt * 16 + lr] = acc[mt][nt][r];
+    __syncthreads();
+    const int cc = lane % CPP;
+    const int co0 = n_base + cc * 8;
+    const bool ch_ok = co0 < a.Cout;
+    float bv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bv[i] = (a.bias && ch_ok) ? a.bias[co0 + i] : 0.f;
+    const int H = a.H, W = a.W;
+#pragma unroll
+    for (int it = 0; it < (32 * CPP) / 64; ++it) {
+        const int row = (it * 64 + lane) / CPP;
+        long m;
+        int n, h, w;
+        const bool ok = pix(row, m, n, h, w) && ch_ok;
+        const f32x4 lo = *(const f32x4*)(wlds + row * LDW + cc * 8);
+        const f32x4 hi = *(const f32x4*)(wlds + row * LDW + cc * 8 + 4);
+        if (!ok) continue;
+        float v[8] = {lo[0] + bv[0], lo[1] + bv[1], lo[2] + bv[2], lo[3] + bv[3], hi[0] + bv[4], hi[1] + bv[5], hi[2] + bv[6], hi[3] + bv[7]};
+        if (a.mask != nullptr) {        // fused ReLU backward of the main path (residual is added after it)
+            const bf16x8 mk = *(const bf16x8*)((const bf16*)a.mask + m * a.Cout + co0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (bf2f(mk[i]) > 0.f) ? v[i] : 0.f;
+        }
+        if (a.ra != nullptr && co0 < a.Ca) {
+            const bf16* ra = (const bf16*)a.ra;
+            float rv[8];
+            if (a.ra_rs == 0) {
+                const bf16x8 t = *(const bf16x8*)(ra + m * a.Cra + co0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) rv[i] = bf2f(t[i]);
+            } else if (a.ra_rs == 1) {      // operand lives at half resolution: nearest x2 upsample
+                const bf16x8 t = *(const bf16x8*)(ra + (((long)n * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1)) * a.Cra + co0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) rv[i] = bf2f(t[i]);
+            } else {                        // operand lives at double resolution: 2x2 average
+                const bf16* p = ra + (((long)n * (2 * H) + 2 * h) * (2 * W) + 2 * w) * a.Cra + co0;
+                const long rs_ = (long)2 * W * a.Cra;
+                const bf16x8 t0 = *(const bf16x8*)p, t1 = *(const bf16x8*)(p + a.Cra), t2 = *(const bf16x8*)(p + rs_),
+                             t3 = *(const bf16x8*)(p + rs_ + a.Cra);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) rv[i] = 0.25f * (bf2f(t0[i]) + bf2f(t1[i]) + bf2f(t2[i]) + bf2f(t3[i]));
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += a.ra_scale * rv[i];
+        } else if (a.rb != nullptr && co0 >= a.Ca) {
+            const bf16x8 t = *(const bf16x8*)((const bf16*)a.rb + m * a.Crb + (co0 - a.Ca));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += bf2f(t[i]);
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            o[i] = f2bf(v[i]);
+            s1[i] += v[i];
+            s2[i] += v[i] * v[i];
+        }
+        *(bf16x8*)((bf16*)a.out + m * a.Cout + co0) = o;
+    }
+    __syncthreads();      // buffer may be reused (second half of a halo tile / next phase)
+}
+
+// fold the per-lane statistics partials (lane owns channel chunk lane % (2*NT)) and add them to the
+// replicated statistics buffer: one atomic per channel per block.
+template <int NT>
+__device__ __forceinline__ void stats_flush(const ConvArgs& a, float (&s1)[8], float (&s2)[8], int n_base, float* red /*[4][NT*16][2]*/,
+                                            int replica) {
+    constexpr int CPP = NT * 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int o = CPP; o < 64; o <<= 1) {
+            s1[i] += __shfl_xor(s1[i], o, 64);
+            s2[i] += __shfl_xor(s2[i], o, 64);
+        }
+    }
+    if (lane < CPP) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            red[(wave * NT * 16 + lane * 8 + i) * 2 + 0] = s1[i];
+            red[(wave * NT * 16 + lane * 8 + i) * 2 + 1] = s2[i];
+        }
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < NT * 16 && n_base + t < a.Cout) {
+        float x1 = 0.f, x2 = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) {
+            x1 += red[(wv * NT * 16 + t) * 2 + 0];
+            x2 += red[(wv * NT * 16 + t) * 2 + 1];
+        }
+        float* st = a.stats + (long)(replica % STAT_REPL) * 2 * a.Cout;
+        atomicAdd(st + n_base + t, x1);
+        atomicAdd(st + a.Cout + n_base + t, x2);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv_gather: block = 4 waves, each wave 2 m-tiles (32 pixels) x NT n-tiles (16*NT channels);
+// A fragments gathered straight from global memory (any H, W; 1x1 and small 3x3 layers).
 // ------------------------------------------------------------------------------------------------
 template <int TAPS, bool AFF, bool RELU, int RS, int NT>
 __global__ __launch_bounds__(256) void conv_gather_kernel(ConvArgs a) {
+    __shared__ __attribute__((aligned(16))) float epi[4 * EpiLds<NT>::FLOATS];
+    __shared__ float red[4 * NT * 16 * 2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 15, lg = lane >> 4;
     const int H = a.H, W = a.W, HW = H * W;
@@ -127,74 +254,24 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(ConvArgs a) {
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfrag[nt], acc[mt][nt], 0, 0, 0);
         }
     }
-
-    // ---------------- epilogue
-    float s1[NT], s2[NT];
+    float s1[8], s2[8];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) s1[nt] = s2[nt] = 0.f;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const long m = m_base + mt * 16 + lg * 4 + r;
-            if (m >= M) continue;
-            int n = 0, h = 0, w = 0;
-            if (a.ra != nullptr && a.ra_rs != 0) {
-                n = (int)(m / HW);
-                const int rem = (int)(m - (long)n * HW);
-                h = rem / W;
-                w = rem - h * W;
-            }
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int co = n_base + nt * 16 + lr;
-                if (NT == 1 && !col_ok) continue;
-                float v = acc[mt][nt][r];
-                if (a.bias) v += a.bias[co];
-                if (a.ra != nullptr && co < a.Ca) {
-                    if (a.ra_rs == 0) {
-                        v += bf2f(((const bf16*)a.ra)[m * a.Cra + co]);
-                    } else if (a.ra_rs == 1) {  // residual lives at half resolution (nearest x2 upsample)
-                        v += bf2f(((const bf16*)a.ra)[(((long)n * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1)) * a.Cra + co]);
-                    } else {                    // residual lives at double resolution (2x2 average pool)
-                        const bf16* p = (const bf16*)a.ra + (((long)n * (2 * H) + 2 * h) * (2 * W) + 2 * w) * a.Cra + co;
-                        const long rs_ = (long)2 * W * a.Cra;
-                        v += 0.25f * (bf2f(p[0]) + bf2f(p[a.Cra]) + bf2f(p[rs_]) + bf2f(p[rs_ + a.Cra]));
-                    }
-                } else if (a.rb != nullptr && co >= a.Ca) {
-                    v += bf2f(((const bf16*)a.rb)[m * a.Crb + (co - a.Ca)]);
-                }
-                if (a.mask != nullptr && !(bf2f(((const bf16*)a.mask)[m * a.Cout + co]) > 0.f)) v = 0.f;
-                ((bf16*)a.out)[m * a.Cout + co] = f2bf(v);
-                s1[nt] += v;
-                s2[nt] += v * v;
-            }
+    for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
+    const bool need_hw = a.ra != nullptr && a.ra_rs != 0;
+    auto pix = [&](int row, long& m, int& n, int& h, int& w) -> bool {
+        m = m_base + row;
+        n = h = w = 0;
+        if (m >= M) return false;
+        if (need_hw) {
+            n = (int)(m / HW);
+            const int rem = (int)(m - (long)n * HW);
+            h = rem / W;
+            w = rem - h * W;
         }
-    }
-    if (a.stats != nullptr) {
-        __shared__ float red[4][NT * 16][2];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            float x1 = s1[nt], x2 = s2[nt];
-            x1 += __shfl_xor(x1, 16, 64);
-            x1 += __shfl_xor(x1, 32, 64);
-            x2 += __shfl_xor(x2, 16, 64);
-            x2 += __shfl_xor(x2, 32, 64);
-            if (lg == 0) {
-                red[wave][nt * 16 + lr][0] = x1;
-                red[wave][nt * 16 + lr][1] = x2;
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < NT * 16 && n_base + (int)threadIdx.x < a.Cout) {
-            const int t = threadIdx.x;
-            const float x1 = red[0][t][0] + red[1][t][0] + red[2][t][0] + red[3][t][0];
-            const float x2 = red[0][t][1] + red[1][t][1] + red[2][t][1] + red[3][t][1];
-            float* st = a.stats + (long)(blockIdx.x % STAT_REPL) * 2 * a.Cout;
-            atomicAdd(st + n_base + t, x1);
-            atomicAdd(st + a.Cout + n_base + t, x2);
-        }
-    }
+        return true;
+    };
+    conv_epilogue<NT>(a, acc, epi + wave * EpiLds<NT>::FLOATS, n_base, pix, s1, s2);
+    if (a.stats != nullptr) stats_flush<NT>(a, s1, s2, n_base, red, blockIdx.x);
 }
 
 template <int TAPS, bool AFF, bool RELU, int RS>
@@ -220,6 +297,134 @@ static int launch_gather_pro(const ConvArgs& a, hipStream_t st) {
     return launch_gather_nt<TAPS, false, false, RS>(a, st);
 }
 
+// ------------------------------------------------------------------------------------------------
+// conv3x3_halo: output tile 8 rows x 32 columns per block.  The (8+2) x (32+2) input halo is staged ONCE
+// in LDS with the prologue (BN apply, ReLU, upsample source mapping) already applied, so the nine taps
+// read transformed bf16 pixels with ds_read_b128 instead of re-gathering and re-transforming from L1.
+// LDS pixel stride = Cin*2 + 16 bytes: 16 consecutive pixels land on 16 distinct 16-byte bank slots.
+// Wave w owns tile rows 2w, 2w+1 (4 m-tiles of 16 pixels).  Weights: global/L1 (small, shared).
+// ------------------------------------------------------------------------------------------------
+#define HT_H 8
+#define HT_W 32
+
+template <bool AFF, bool RELU, int RS, int NT>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(ConvArgs a, int tiles_w, int tiles_h, int nblk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float red[4 * NT * 16 * 2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int H = a.H, W = a.W, Cin = a.Cin;
+    const int PS = Cin * 2 + 16;                           // bytes per halo pixel
+    // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2), so give each XCD a contiguous
+    // run of tiles -- neighbouring tiles then share their halo rows / weights through one L2.
+    int bid = blockIdx.x;
+    {
+        const int q = nblk / 8, r = nblk % 8, xcd = bid % 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+    }
+    const int n = bid / (tiles_w * tiles_h);
+    const int trem = bid - n * tiles_w * tiles_h;
+    const int h0 = (trem / tiles_w) * HT_H, w0 = (trem % tiles_w) * HT_W;
+    const int n_base = blockIdx.y * NT * 16;
+    constexpr int AW = HT_W + 2, AH = HT_H + 2;
+
+    // ---- stage the halo
+    const int chunks = Cin >> 3;
+    for (int idx = threadIdx.x; idx < AH * AW * chunks; idx += 256) {
+        const int hp = idx / chunks, cc = idx - hp * chunks;
+        const int hh = h0 - 1 + hp / AW, ww = w0 - 1 + hp % AW;
+        const bf16x8 v = gather8<AFF, RELU, RS>(a.src, H, W, n, hh, ww, cc * 8, true);
+        *(bf16x8*)(smem + hp * PS + cc * 16) = v;
+    }
+    __syncthreads();
+
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int ksteps = a.Kpad >> 5;
+    const bool col_ok = (n_base + (NT - 1) * 16 + lr) < a.Cout;
+    const bf16* wrow = (const bf16*)a.w + (long)(col_ok ? n_base + lr : 0) * a.Kpad + lg * 8;
+    // byte offset of this lane's pixel in m-tile mt at tap (0,0): row 2*wave + (mt>>1), col (mt&1)*16 + lr
+    int pbase[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) pbase[mt] = ((2 * wave + (mt >> 1)) * AW + (mt & 1) * 16 + lr) * PS;
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const int k = ks * 32 + lg * 8;
+        int tap = k / Cin;
+        const int c = k - tap * Cin;
+        const bool kval = tap < 9;
+        if (!kval) tap = 0;
+        const int toff = ((tap / 3) * AW + (tap - (tap / 3) * 3)) * PS + c * 2;
+        bf16x8 bfrag[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            bfrag[nt] = *(const bf16x8*)(wrow + (long)nt * 16 * a.Kpad + ks * 32);
+            if (NT == 1 && !col_ok) bfrag[nt] = zero8();
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            bf16x8 af = *(const bf16x8*)(smem + pbase[mt] + toff);
+            if (!kval) af = zero8();
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfrag[nt], acc[mt][nt], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                       // halo no longer needed: reuse LDS for the epilogue
+    float* epi = (float*)smem + wave * EpiLds<NT>::FLOATS;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {                 // tile row 2*wave + half: 32 pixels
+        const int hh = h0 + 2 * wave + half;
+        auto pix = [&](int row, long& m, int& nn, int& h, int& w) -> bool {
+            nn = n;
+            h = hh;
+            w = w0 + row;
+            m = ((long)n * H + h) * W + w;
+            return h < H && w < W;
+        };
+        const f32x4(&sub)[2][NT] = *reinterpret_cast<const f32x4(*)[2][NT]>(&acc[2 * half]);
+        conv_epilogue<NT>(a, sub, epi, n_base, pix, s1, s2);
+    }
+    if (a.stats != nullptr) stats_flush<NT>(a, s1, s2, n_base, red, bid);
+}
+
+template <bool AFF, bool RELU, int RS>
+static int launch_halo_nt(const ConvArgs& a, hipStream_t st) {
+    const int tiles_w = (a.W + HT_W - 1) / HT_W, tiles_h = (a.H + HT_H - 1) / HT_H;
+    const int nblk = a.N * tiles_w * tiles_h;
+    const size_t halo = (size_t)(HT_H + 2) * (HT_W + 2) * (a.Cin * 2 + 16);
+#define HALO_LAUNCH(NTV)                                                                                     \
+    {                                                                                                        \
+        size_t lds = halo;                                                                                   \
+        const size_t epi = (size_t)4 * EpiLds<NTV>::FLOATS * 4;                                              \
+        if (epi > lds) lds = epi;                                                                            \
+        hipLaunchKernelGGL((conv3x3_halo_kernel<AFF, RELU, RS, NTV>), dim3(nblk, (a.Cout + 16 * NTV - 1) / (16 * NTV)), \
+                           dim3(256), lds, st, a, tiles_w, tiles_h, nblk);                                   \
+    }
+    if (a.Cout % 64 == 0) HALO_LAUNCH(4)
+    else if (a.Cout % 32 == 0) HALO_LAUNCH(2)
+    else HALO_LAUNCH(1)
+#undef HALO_LAUNCH
+    return 0;
+}
+
+template <int RS>
+static int launch_halo_pro(const ConvArgs& a, hipStream_t st) {
+    const bool aff = a.src.scale != nullptr, relu = a.src.relu != 0;
+    if (aff && relu) return launch_halo_nt<true, true, RS>(a, st);
+    if (aff) return launch_halo_nt<true, false, RS>(a, st);
+    if (relu) return launch_halo_nt<false, true, RS>(a, st);
+    return launch_halo_nt<false, false, RS>(a, st);
+}
+
+static int g_force_gather = 0;      // tests: run 3x3 layers through the gather kernel
+void conv_force_gather(int on) { g_force_gather = on; }
+
 int conv_gather_launch(const ConvArgs& a, hipStream_t st) {
     CHECK_ARG(a.taps == 1 || a.taps == 9, "conv: taps must be 1 or 9 (got %d)", a.taps);
     CHECK_ARG(a.Cin % 8 == 0 && a.Cout % 8 == 0, "conv: Cin/Cout must be multiples of 8 (%d,%d)", a.Cin, a.Cout);
@@ -230,13 +435,18 @@ int conv_gather_launch(const ConvArgs& a, hipStream_t st) {
     if (a.src.rs == 1) CHECK_ARG(a.H == 2 * a.src.Hs && a.W == 2 * a.src.Ws, "conv: upsample geometry mismatch");
     if (a.src.rs == 2) CHECK_ARG(2 * a.H == a.src.Hs && 2 * a.W == a.src.Ws, "conv: pool geometry mismatch");
     if (a.src.rs == 0) CHECK_ARG(a.H == a.src.Hs && a.W == a.src.Ws, "conv: geometry mismatch");
-    if (a.ra) CHECK_ARG(a.Ca <= a.Cout && a.Ca <= a.Cra, "conv: residual channel slice out of range");
+    if (a.ra) CHECK_ARG(a.Ca <= a.Cout && a.Ca <= a.Cra && a.Ca % 8 == 0 && a.Cra % 8 == 0, "conv: residual channel slice out of range");
     if (a.ra && a.ra_rs == 1) CHECK_ARG(a.H % 2 == 0 && a.W % 2 == 0, "conv: upsampled residual needs even H, W");
+    if (a.rb) CHECK_ARG(a.Crb % 8 == 0 && a.Crb >= a.Cout - a.Ca, "conv: bad residual-B channel count");
     const double flops = 2.0 * a.N * a.H * a.W * (double)a.Cout * a.taps * a.Cin;
     const double bytes = 2.0 * a.N * ((double)a.src.Hs * a.src.Ws * a.Cin + (double)a.H * a.W * a.Cout);
-    ProfScope prof(a.taps == 9 ? "conv3x3_gather" : "conv1x1_gather", flops, bytes, st);
+    const bool halo = a.taps == 9 && a.src.rs != 2 && a.W >= 16 && a.H >= 4 && a.Cin % 16 == 0 && !g_force_gather &&
+                      (size_t)(HT_H + 2) * (HT_W + 2) * (a.Cin * 2 + 16) <= 150 * 1024;
+    ProfScope prof(a.taps == 9 ? (halo ? "conv3x3_halo" : "conv3x3_gather") : "conv1x1_gather", flops, bytes, st);
     int rc;
-    if (a.taps == 9) {
+    if (halo) {
+        rc = (a.src.rs == 0) ? launch_halo_pro<0>(a, st) : launch_halo_pro<1>(a, st);
+    } else if (a.taps == 9) {
         if (a.src.rs == 0) rc = launch_gather_pro<9, 0>(a, st);
         else if (a.src.rs == 1) rc = launch_gather_pro<9, 1>(a, st);
         else { ieagan_set_error("conv: 3x3 with pooled source is not instantiated"); return IEAGAN_EINVAL; }
@@ -245,7 +455,7 @@ int conv_gather_launch(const ConvArgs& a, hipStream_t st) {
         else if (a.src.rs == 2) rc = launch_gather_pro<1, 2>(a, st);
         else { ieagan_set_error("conv: 1x1 with upsampled source is not instantiated"); return IEAGAN_EINVAL; }
     }
-    CHECK_LAUNCH("conv_gather");
+    CHECK_LAUNCH("conv_forward");
     return rc;
 }
 

@@ -101,8 +101,9 @@ class GBlock(nn.Module):
         up = 1 if self.upsample else 0
         cnt = N * Hh * Ww
         tr = self.training
+        link = ops.ResLink() if (torch.is_grad_enabled() and ops.FUSE_SHORTCUT_GRAD) else None   # conv4 -> conv1, in-kernel
         s, t = self.bn1.scale_shift(xstats, bank, *cols["bn1"], cnt)
-        h, st = self.conv1.fused(xa, recs[prefix + ".conv1"], scale=s, shift=t, relu=True, want_stats=tr)
+        h, st = self.conv1.fused(xa, recs[prefix + ".conv1"], scale=s, shift=t, relu=True, want_stats=tr, res_in=link)
         s, t = self.bn2.scale_shift(st, bank, *cols["bn2"], cnt)
         h, st = self.conv2.fused(h, recs[prefix + ".conv2"], scale=s, shift=t, relu=True, rs=up, want_stats=tr)
         cnt2 = cnt * (4 if up else 1)
@@ -110,7 +111,7 @@ class GBlock(nn.Module):
         h, st = self.conv3.fused(h, recs[prefix + ".conv3"], scale=s, shift=t, relu=True, want_stats=tr)
         s, t = self.bn4.scale_shift(st, bank, *cols["bn4"], cnt2)
         return self.conv4.fused(h, recs[prefix + ".conv4"], scale=s, shift=t, relu=True, ra=xa, Ca=self.out_channels,
-                                ra_rs=up, want_stats=want_stats and tr)
+                                ra_rs=up, want_stats=want_stats and tr, res_out=link)
 
     def forward(self, x, y):
         """Stand-alone block on NCHW fp32 ``x`` with the conditioning vector ``y`` [N, cond]."""
@@ -263,13 +264,15 @@ class DBlock(nn.Module):
 
     def fused(self, xa, recs, prefix):
         rs = 2 if self.downsample else 0
-        h, _ = self.conv1.fused(xa, recs[prefix + ".conv1"], relu=self.preactivation)
+        link = ops.ResLink() if (torch.is_grad_enabled() and ops.FUSE_SHORTCUT_GRAD) else None   # conv4 (-> conv_sc) -> conv1
+        h, _ = self.conv1.fused(xa, recs[prefix + ".conv1"], relu=self.preactivation, res_in=link)
         h, _ = self.conv2.fused(h, recs[prefix + ".conv2"], relu=True)
         h, _ = self.conv3.fused(h, recs[prefix + ".conv3"], relu=True)
         sc = None
         if self.learnable_sc:   # conv_sc sees the pooled, un-activated block input (model.py:534-539)
-            sc, _ = self.conv_sc.fused(xa, recs[prefix + ".conv_sc"], rs=rs)
-        out, _ = self.conv4.fused(h, recs[prefix + ".conv4"], relu=True, rs=rs, ra=xa, Ca=self.in_channels, ra_rs=rs, rb=sc)
+            sc, _ = self.conv_sc.fused(xa, recs[prefix + ".conv_sc"], rs=rs, res_in=link if rs == 2 else None)
+        out, _ = self.conv4.fused(h, recs[prefix + ".conv4"], relu=True, rs=rs, ra=xa, Ca=self.in_channels, ra_rs=rs, rb=sc,
+                                  res_out=link)
         return out
 
     def forward(self, x):

@@ -277,18 +277,43 @@ class BNFinalizePlainFn(torch.autograd.Function):
 # Fused convolution
 # =====================================================================================================
 def _conv_launch(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu, N, Hc, Wc, Cin, Cout, taps, kpad, w, bias,
-                 ra, Cra, Ca, ra_rs, rb, Crb, mask, out, stats):
+                 ra, Cra, Ca, ra_rs, rb, Crb, mask, out, stats, ra_scale=1.0):
     d = H.ConvDesc(N, Hc, Wc, Cin, Cout, taps, kpad, H.src_desc(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu),
-                   H.ptr(w), H.ptr(bias), H.ptr(ra), Cra, Ca, ra_rs, H.ptr(rb), Crb, H.ptr(mask), H.ptr(out), H.ptr(stats))
+                   H.ptr(w), H.ptr(bias), H.ptr(ra), Cra, Ca, ra_rs, float(ra_scale), H.ptr(rb), Crb, H.ptr(mask),
+                   H.ptr(out), H.ptr(stats))
     H.call("ieagan_conv_forward", d, H.stream())
 
 
 USE_TR_READ = True        # ds_read_b64_tr_b16 operand reads in conv_wgrad (False: scalar LDS reads)
+FUSE_SHORTCUT_GRAD = True # add residual-shortcut gradients inside the dx-producing kernel (False: autograd adds)
+
+
+class ResLink:
+    """Hand-off of a shortcut gradient between two convs of one residual block.
+
+    The block input x feeds both the first conv (through its prologue) and the last conv's residual
+    operand.  Instead of letting autograd materialise and add two full-size gradients for x, the last
+    conv's backward *deposits* its out-grad here and the first conv's backward adds it inside the kernel
+    that produces dx anyway (prologue_bwd, or the dgrad epilogue when the prologue is a bare ReLU)."""
+    __slots__ = ("g", "C", "Ca", "mode", "ready")
+
+    def __init__(self):
+        self.g, self.C, self.Ca, self.mode, self.ready = None, 0, 0, 0, False
+
+    def deposit(self, g, C, Ca, mode):
+        self.g, self.C, self.Ca, self.mode, self.ready = g, C, Ca, mode, True
+
+    def take(self):
+        if not self.ready:
+            raise RuntimeError("shortcut gradient requested before it was produced (autograd order changed?)")
+        out = (self.g, self.C, self.Ca, self.mode)
+        self.g, self.ready = None, False
+        return out
 
 
 class ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, scale, shift, ra, rb, rec, taps, rs, relu, Ca, ra_rs, want_stats):
+    def forward(ctx, x, weight, bias, scale, shift, ra, rb, rec, taps, rs, relu, Ca, ra_rs, want_stats, res_out, res_in):
         N, Hs, Ws, Cx = x.shape
         Cout, Cin = rec.out, rec.cin
         assert x.dtype == BF16 and x.is_contiguous() and Cx == Cin, (x.dtype, x.shape, Cin)
@@ -302,8 +327,8 @@ class ConvFn(torch.autograd.Function):
         ctx.rec, ctx.cfg = rec, (taps, rs, relu, Ca, ra_rs, nstride, Hc, Wc)
         ctx.ra_shape = ra.shape if ra is not None else None
         ctx.has = (bias is not None, scale is not None, ra is not None, rb is not None)
+        ctx.links = (res_out, res_in)
         ctx.save_for_backward(x, weight, scale, shift, out if want_stats else None)
-        ctx.mark_non_differentiable()
         return out, stats
 
     @staticmethod
@@ -312,6 +337,7 @@ class ConvFn(torch.autograd.Function):
         rec = ctx.rec
         taps, rs, relu, Ca, ra_rs, nstride, Hc, Wc = ctx.cfg
         has_bias, has_aff, has_ra, has_rb = ctx.has
+        res_out, res_in = ctx.links
         N, Hs, Ws, Cx = x.shape
         Cout, Cin = rec.out, rec.cin
         dev = x.device
@@ -335,7 +361,9 @@ class ConvFn(torch.autograd.Function):
         d_ra = d_rb = None
         if has_ra and need[5]:
             rshape = ctx.ra_shape
-            if ra_rs == 0:
+            if res_out is not None:
+                res_out.deposit(g, Cout, Ca, ra_rs)            # consumed in-kernel by the block's first conv
+            elif ra_rs == 0:
                 if Ca == Cout and rshape[-1] == Cout:
                     d_ra = g
                 else:
@@ -352,17 +380,44 @@ class ConvFn(torch.autograd.Function):
         if need[0] or (has_aff and (need[3] or need[4])):
             da = torch.empty(N, Hc, Wc, Cin, dtype=BF16, device=dev)
             fuse_mask = relu and not has_aff and rs == 0
-            _conv_launch(g, Cout, Hc, Wc, 0, None, None, 0, False, N, Hc, Wc, Cout, Cin, taps, rec.kpad2, rec.w_bwd, None,
-                         None, 0, 0, 0, None, 0, x if fuse_mask else None, da, None)
-            if fuse_mask or (not relu and not has_aff and rs == 0):
+            plain = not relu and not has_aff
+            lg = lC = lCa = lmode = None
+            if res_in is not None and not res_in.ready:
+                res_in = None          # the shortcut operand needed no gradient (e.g. a detached block input)
+            if res_in is not None:
+                lg, lC, lCa, lmode = res_in.take()
+            if res_in is not None and (fuse_mask or (plain and rs == 0)):
+                # bare-ReLU / no prologue (D blocks): the dgrad epilogue masks the main path and adds the
+                # shortcut gradient (0.25 * nearest-expand when the shortcut was average-pooled)
+                _conv_launch(g, Cout, Hc, Wc, 0, None, None, 0, False, N, Hc, Wc, Cout, Cin, taps, rec.kpad2, rec.w_bwd, None,
+                             lg, lC, lCa, 1 if lmode == 2 else 0, None, 0, x if fuse_mask else None, da, None,
+                             ra_scale=0.25 if lmode == 2 else 1.0)
                 dx = da
+            elif res_in is not None and plain and rs == 2 and res_out is None:
+                # conv_sc of a D block (pooled, un-activated input): chain -- add the deposited shortcut
+                # gradient at the pooled resolution and re-deposit the sum for the block's first conv
+                _conv_launch(g, Cout, Hc, Wc, 0, None, None, 0, False, N, Hc, Wc, Cout, Cin, taps, rec.kpad2, rec.w_bwd, None,
+                             lg, lC, lCa, 0, None, 0, None, da, None)
+                res_in.deposit(da, Cin, Cin, 2)
+                dx = None
             else:
-                dx = torch.empty(N, Hs, Ws, Cin, dtype=BF16, device=dev)
-                if has_aff:
-                    dscale = torch.zeros_like(scale)
-                    dshift = torch.zeros_like(shift)
-                H.call("ieagan_prologue_bwd", da.data_ptr(), x.data_ptr(), Cx, H.ptr(scale), H.ptr(shift), nstride, int(relu),
-                       rs, dx.data_ptr(), H.ptr(dscale), H.ptr(dshift), N, Hs, Ws, Cin, H.stream())
+                _conv_launch(g, Cout, Hc, Wc, 0, None, None, 0, False, N, Hc, Wc, Cout, Cin, taps, rec.kpad2, rec.w_bwd, None,
+                             None, 0, 0, 0, None, 0, x if fuse_mask else None, da, None)
+                if (fuse_mask or (plain and rs == 0)) and res_in is None:
+                    dx = da
+                else:
+                    dx = torch.empty(N, Hs, Ws, Cin, dtype=BF16, device=dev)
+                    if has_aff:
+                        dscale = torch.zeros_like(scale)
+                        dshift = torch.zeros_like(shift)
+                    rmode = 0
+                    if res_in is not None:
+                        if lmode == 2:
+                            raise RuntimeError("pooled shortcut gradient cannot be added by prologue_bwd")
+                        rmode = lmode
+                    H.call("ieagan_prologue_bwd", da.data_ptr(), x.data_ptr(), Cx, H.ptr(scale), H.ptr(shift), nstride, int(relu),
+                           rs, dx.data_ptr(), H.ptr(dscale), H.ptr(dshift), N, Hs, Ws, Cin, H.ptr(lg), lC or 0, lCa or 0, rmode,
+                           H.stream())
         # ---- weight gradient (skipped entirely when the parameter is frozen, e.g. D in the G phase)
         dW = None
         if need[1]:
@@ -371,12 +426,12 @@ class ConvFn(torch.autograd.Function):
                             H.src_desc(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu), g.data_ptr(), Cout, dwp.data_ptr(), 0)
             H.call("ieagan_conv_wgrad", d, int(USE_TR_READ), H.stream())
             dW = sn_backward(dwp, weight, rec)
-        return dx, dW, dbias, dscale, dshift, d_ra, d_rb, None, None, None, None, None, None, None
+        return dx, dW, dbias, dscale, dshift, d_ra, d_rb, None, None, None, None, None, None, None, None, None
 
 
 def conv(x, weight, bias, rec, taps, *, scale=None, shift=None, relu=False, rs=0, ra=None, Ca=0, ra_rs=0, rb=None,
-         want_stats=False):
-    return ConvFn.apply(x, weight, bias, scale, shift, ra, rb, rec, taps, rs, relu, Ca, ra_rs, want_stats)
+         want_stats=False, res_out=None, res_in=None):
+    return ConvFn.apply(x, weight, bias, scale, shift, ra, rb, rec, taps, rs, relu, Ca, ra_rs, want_stats, res_out, res_in)
 
 
 # =====================================================================================================
@@ -454,7 +509,7 @@ class OutputConvFn(torch.autograd.Function):
             dh = torch.empty_like(h)
             dscale, dshift = torch.zeros_like(scale), torch.zeros_like(shift)
             H.call("ieagan_prologue_bwd", da.data_ptr(), h.data_ptr(), C, scale.data_ptr(), shift.data_ptr(), 0, 1, 0,
-                   dh.data_ptr(), dscale.data_ptr(), dshift.data_ptr(), N, Hh, Ww, C, H.stream())
+                   dh.data_ptr(), dscale.data_ptr(), dshift.data_ptr(), N, Hh, Ww, C, None, 0, 0, 0, H.stream())
         if need[3]:
             dw = torch.zeros(9, C, dtype=torch.float32, device=dev)
             H.call("ieagan_wgrad_c1", dpre.data_ptr(), None, h.data_ptr(), scale.data_ptr(), shift.data_ptr(), 0, 1, dw.data_ptr(),

@@ -54,6 +54,8 @@ typedef struct {
     const float* bias;    /* [Cout] or NULL                                                     */
     const void* ra;       /* residual A: bf16, channels [0,Ca) of a tensor with Cra channels    */
     int Cra, Ca, ra_rs;   /* ra_rs 0 same | 1 residual at half res | 2 residual at double res   */
+    float ra_scale;       /* out += ra_scale * resample(ra)  (1 in forward; 4 / 0.25 when the    */
+                          /* epilogue adds a shortcut GRADIENT: 2x2 sum / 0.25 * expand)         */
     const void* rb;       /* residual B: bf16 [N,H,W,Crb] feeding channels [Ca, Cout)           */
     int Crb;
     const void* mask;     /* bf16 [N,H,W,Cout]: output zeroed where mask <= 0, or NULL          */
@@ -61,6 +63,7 @@ typedef struct {
     float* stats;         /* fp32 [32][2][Cout] replicated (sum, sumsq), accumulated; or NULL   */
 } ieagan_conv_desc;
 int ieagan_conv_forward(const ieagan_conv_desc* d, void* stream);
+int ieagan_conv_force_gather(int on);   /* tests: route 3x3 layers through the gather kernel   */
 
 /* ---- weight gradient: dWp[Cout][Kpad] += G^T A   (autograd of F.conv2d w.r.t. weight) -------- */
 typedef struct {
@@ -79,10 +82,12 @@ int ieagan_conv_wgrad(const ieagan_wgrad_desc* d, int use_tr_read, void* stream)
  * Autograd of F.batch_norm's batch statistics folded into the producer's out-grad. */
 int ieagan_effgrad(const void* dout, const void* out, const float* dstat, void* geff, float* colsum,
                    long P, int C, void* stream);
-/* backward of the fused prologue: dx, and per-(n,c) d scale / d shift (atomically accumulated) */
+/* backward of the fused prologue: dx, and per-(n,c) d scale / d shift (atomically accumulated).
+ * radd (optional): gradient of a shortcut that read the same x (channels [0,Ca) of a tensor with Cr
+ * channels; rmode 0 same resolution, 1 = 2x2 sum of a tensor at double resolution), added into dx. */
 int ieagan_prologue_bwd(const void* da, const void* x, int Cx, const float* scale, const float* shift,
                         int nstride, int relu, int rs, void* dx, float* dscale, float* dshift,
-                        int N, int Hs, int Ws, int C, void* stream);
+                        int N, int Hs, int Ws, int C, const void* radd, int Cr, int Ca, int rmode, void* stream);
 /* ccbn / bn statistics -> scale/shift (+ running-stat update), layers.py:656-689, 728-742 */
 int ieagan_bn_finalize_fwd(const float* stats, float count, const float* gain, const float* bias, int ld,
                            int plus_one, float eps, float momentum, int training, float* run_mean,

@@ -126,7 +126,32 @@ CONV_CASES = [
     (1, 32, 32, 4, 6, False, False, 2, None, False),             # DBlock.conv_sc on the pooled input
     (1, 512, 128, 4, 12, True, True, 0, None, True),
     (1, 128, 512, 4, 12, False, True, 0, None, False),
+    (9, 32, 32, 17, 48, True, True, 0, None, True),          # halo kernel, ragged rows (17 % 8 != 0)
+    (9, 16, 16, 24, 96, False, True, 0, None, False),        # halo kernel, Cin = 16 (two taps per MFMA K step)
+    (9, 128, 128, 8, 24, True, True, 0, None, True),         # halo kernel, ragged columns (24 % 32 != 0), 2 cout chunks
+    (9, 64, 64, 8, 24, True, True, 1, None, True),           # halo kernel with upsampled source
 ]
+
+
+def test_halo_and_gather_kernels_agree(dev):
+    """The LDS-halo 3x3 kernel and the direct-gather kernel compute the same convolution."""
+    import _hip, ops
+    torch.manual_seed(7)
+    N, Hh, Ww, Cin, Cout = 2, 19, 40, 32, 64
+    x = torch.randn(N, Hh, Ww, Cin, device=dev).to(BF)
+    w = (torch.randn(Cout, 9 * Cin, device=dev) / 17).to(BF)
+    sc, sh = 1 + 0.3 * torch.randn(N, Cin, device=dev), 0.2 * torch.randn(N, Cin, device=dev)
+    outs = []
+    for force in (0, 1):
+        _hip.call("ieagan_conv_force_gather", force)
+        out = torch.empty(N, Hh, Ww, Cout, device=dev, dtype=BF)
+        st = ops.new_stats(Cout, dev)
+        ops._conv_launch(x, Cin, Hh, Ww, 0, sc, sh, Cin, True, N, Hh, Ww, Cin, Cout, 9, 9 * Cin, w, None, None, 0, 0, 0, None, 0,
+                         None, out, st)
+        outs.append((out, st.sum(0)))
+    _hip.call("ieagan_conv_force_gather", 0)
+    close(outs[0][0], outs[1][0], 4e-3, "halo vs gather out")
+    close(outs[0][1], outs[1][1], 1e-3, "halo vs gather stats")
 
 
 def conv_reference(x, W, u, bias, scale, shift, relu, rs, taps, ra, ra_mode, Ca, rb):

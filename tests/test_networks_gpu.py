@@ -8,7 +8,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from parity_util import TOL, forward_parity, rel_l2, step_parity  # noqa: E402
+from parity_util import TOL, cosine, forward_parity, rel_l2, step_parity  # noqa: E402
 
 
 def test_forward_64_vs_oracle_and_golden(golden_dir):
@@ -80,3 +80,95 @@ def test_full_resolution_properties():
         a = D(gz, y)[2]
         b = D(gz, y)[2]
     assert torch.equal(a, b)
+
+
+def _load_block(module, seed):
+    from parity_util import O
+    spec = {k: tuple(v.shape) for k, v in module.state_dict().items()}
+    module.load_state_dict(O.synth_state(spec, seed))
+    return module.cuda().train()
+
+
+@pytest.mark.parametrize("tag,cin,cout,up", [("up", 64, 32, True), ("same", 64, 64, False)])
+def test_gblock_vs_golden(golden_dir, ref_cfg, tag, cin, cout, up):
+    """Stand-alone GBlock (module-boundary NCHW fp32) against the reference-generated vectors:
+    output, input / conditioning gradients and every weight gradient (incl. the sigma term)."""
+    import functools
+    import layers, model
+    import torch.nn.functional as F
+    g = np.load(os.path.join(golden_dir, f"op_gblock_{tag}.npz"))
+    lin = functools.partial(layers.SNLinear, bias=False, eps=ref_cfg["SN_eps"])
+    blk = model.GBlock(cin, cout, functools.partial(layers.SNConv2d, kernel_size=3, padding=1, eps=ref_cfg["SN_eps"]),
+                       functools.partial(layers.ccbn, which_linear=lin, input_size=256, eps=ref_cfg["BN_eps"]),
+                       torch.nn.ReLU(inplace=True), functools.partial(F.interpolate, scale_factor=2) if up else None)
+    blk = _load_block(blk, 15)
+    x = torch.from_numpy(g["x"]).cuda().requires_grad_(True)
+    yv = torch.from_numpy(g["yv"]).cuda().requires_grad_(True)
+    y = blk(x, yv)
+    assert rel_l2(y, torch.from_numpy(g["y"])) <= 2e-2
+    names = [k[3:] for k in g.files if k.startswith("gw.")]
+    params = dict(blk.named_parameters())
+    grads = torch.autograd.grad(y, [x, yv] + [params[n] for n in names], torch.from_numpy(g["go"]).cuda())
+    # four stacked bf16 convs + three ReLU masks: gradients carry a few % of rounding noise (the fp32
+    # per-op tests in test_hip_ops.py are the tight ones); a wrong term would show up as O(1)
+    assert rel_l2(grads[0], torch.from_numpy(g["gx"])) <= 8e-2 and cosine(grads[0], torch.from_numpy(g["gx"])) >= 0.995
+    # d/dy sums d(scale), d(shift) over only 48-192 pixels here: near-cancelling sums amplify bf16 noise
+    assert rel_l2(grads[1], torch.from_numpy(g["gy"])) <= 0.15 and cosine(grads[1], torch.from_numpy(g["gy"])) >= 0.99
+    for n, gr in zip(names, grads[2:]):
+        assert rel_l2(gr, torch.from_numpy(g["gw." + n])) <= 8e-2, n
+    # the in-kernel shortcut-gradient path equals the autograd-summed path up to one bf16 rounding
+    import ops
+    ops.FUSE_SHORTCUT_GRAD = False
+    try:
+        blk2 = _load_block(model.GBlock(cin, cout, blk.which_conv, blk.which_bn, blk.activation, blk.upsample), 15)
+        x2 = x.detach().clone().requires_grad_(True)
+        (gx2,) = torch.autograd.grad(blk2(x2, yv.detach()), [x2], torch.from_numpy(g["go"]).cuda())
+    finally:
+        ops.FUSE_SHORTCUT_GRAD = True
+    assert rel_l2(grads[0], gx2) <= 1e-2
+
+
+@pytest.mark.parametrize("tag,cin,cout,down,pre", [("down", 32, 64, True, True), ("first", 32, 64, True, False),
+                                                   ("same", 64, 64, False, True)])
+def test_dblock_vs_golden(golden_dir, ref_cfg, tag, cin, cout, down, pre):
+    import functools
+    import layers, model
+    g = np.load(os.path.join(golden_dir, f"op_dblock_{tag}.npz"))
+    blk = model.DBlock(cin, cout, functools.partial(layers.SNConv2d, kernel_size=3, padding=1, eps=ref_cfg["SN_eps"]), True, pre,
+                       torch.nn.ReLU(inplace=True), torch.nn.AvgPool2d(2) if down else None)
+    blk = _load_block(blk, 16)
+    x = torch.from_numpy(g["x"]).cuda().requires_grad_(True)
+    y = blk(x)
+    assert rel_l2(y, torch.from_numpy(g["y"])) <= 2e-2
+    names = [k[3:] for k in g.files if k.startswith("gw.")]
+    params = dict(blk.named_parameters())
+    grads = torch.autograd.grad(y, [x] + [params[n] for n in names], torch.from_numpy(g["go"]).cuda())
+    assert rel_l2(grads[0], torch.from_numpy(g["gx"])) <= 8e-2 and cosine(grads[0], torch.from_numpy(g["gx"])) >= 0.995
+    for n, gr in zip(names, grads[1:]):
+        assert rel_l2(gr, torch.from_numpy(g["gw." + n])) <= 8e-2, n
+    import ops
+    ops.FUSE_SHORTCUT_GRAD = False
+    try:
+        blk2 = _load_block(model.DBlock(cin, cout, blk.which_conv, True, pre, blk.activation, blk.downsample), 16)
+        x2 = x.detach().clone().requires_grad_(True)
+        (gx2,) = torch.autograd.grad(blk2(x2), [x2], torch.from_numpy(g["go"]).cuda())
+    finally:
+        ops.FUSE_SHORTCUT_GRAD = True
+    assert rel_l2(grads[0], gx2) <= 1e-2
+
+
+def test_attention_vs_golden(golden_dir, ref_cfg):
+    import functools
+    import layers
+    g = np.load(os.path.join(golden_dir, "op_attention.npz"))
+    att = layers.Attention(64, functools.partial(layers.SNConv2d, kernel_size=3, padding=1, eps=ref_cfg["SN_eps"]))
+    att = _load_block(att, 17)
+    x = torch.from_numpy(g["x"]).cuda().requires_grad_(True)
+    y = att(x)
+    assert rel_l2(y, torch.from_numpy(g["y"])) <= 2e-2
+    names = [k[3:] for k in g.files if k.startswith("gw.")]
+    params = dict(att.named_parameters())
+    grads = torch.autograd.grad(y, [x] + [params[n] for n in names], torch.from_numpy(g["go"]).cuda())
+    assert rel_l2(grads[0], torch.from_numpy(g["gx"])) <= 4e-2
+    for n, gr in zip(names, grads[1:]):
+        assert rel_l2(gr, torch.from_numpy(g["gw." + n])) <= 6e-2, n
