@@ -67,8 +67,8 @@ _SIGS = {
     "ieagan_diffaug_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, vp],
     "ieagan_diffaug_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, vp],
     "ieagan_cr_diffaug": [vp, vp, vp, vp, vp, i, i, i, vp],
-    "ieagan_adam_step": [vp, vp, vp, vp, l, f, f, f, f, i, f, vp],
-    "ieagan_ema_update": [vp, vp, l, f, vp],
+    "ieagan_adam_step": [vp, vp, vp, vp, l, vp, vp],
+    "ieagan_ema_update": [vp, vp, l, vp, vp],
     "ieagan_selftest_tr_read": [vp, vp, vp],
 }
 EXPORTS = ["ieagan_last_error"] + list(_SIGS)

@@ -17,14 +17,6 @@ struct AugDraws {
     const long* oy;
 };
 
-__device__ __forceinline__ bool aug_keep(int h, int w, int H, int W, int tx, int ty, int ox, int oy) {
-    // output pixel (h,w) reads source (h+tx, w+ty); zero when that is outside or (h,w) is cut out
-    const int hs = h + tx, ws = w + ty;
-    if (hs < 0 || hs >= H || ws < 0 || ws >= W) return false;
-    const int ch = (H + 1) / 2 - ((H % 2) ? 0 : 0);  // int(H*0.5+0.5)
-    return true & (ch >= 0);
-}
-
 __device__ __forceinline__ bool in_cut(int h, int w, int H, int W, int ox, int oy) {
     const int ch = (int)(H * 0.5f + 0.5f), cw = (int)(W * 0.5f + 0.5f);
     int r0 = ox - ch / 2, r1 = ox - ch / 2 + ch - 1;
@@ -166,9 +158,20 @@ extern "C" int ieagan_cr_diffaug(const float* x, const float* flip_u, const long
 // ------------------------------------------------------------------------------------------------
 // flat-arena optimiser kernels (float4 per lane)
 // ------------------------------------------------------------------------------------------------
+// Hyper-parameters live in device memory so that a captured HIP graph of the train step stays valid
+// while the step counter / learning rate / EMA decay change:
+//   hp[0] lr, hp[1] beta1, hp[2] beta2, hp[3] eps, hp[4] step (as float), hp[5] grad scale,
+//   hp[6] lr / (1 - beta1^step), hp[7] 1 / sqrt(1 - beta2^step)      (written by adam_tick)
+__global__ void adam_tick_kernel(float* __restrict__ hp) {
+    const float step = hp[4] + 1.f;
+    hp[4] = step;
+    hp[6] = hp[0] / (1.f - powf(hp[1], step));
+    hp[7] = rsqrtf(1.f - powf(hp[2], step));
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, long n, float lr_bc1, float b1, float b2, float eps,
-                                                   float inv_sqrt_bc2, float gscale) {
+                                                   float* __restrict__ v, long n, const float* __restrict__ hp) {
+    const float b1 = hp[1], b2 = hp[2], eps = hp[3], gscale = hp[5], lr_bc1 = hp[6], inv_sqrt_bc2 = hp[7];
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const float gi = g[i] * gscale;
         const float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -179,27 +182,27 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
-extern "C" int ieagan_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
-                                int step, float gscale, void* stream) {
+extern "C" int ieagan_adam_step(float* p, const float* g, float* m, float* v, long n, float* hp, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    CHECK_ARG(step >= 1, "adam: step must be >= 1");
+    CHECK_ARG(hp != nullptr, "adam: hyper-parameter block missing");
     ProfScope prof("adam_step", 0.0, 28.0 * n, st);
-    const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
     long blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, n, (float)(lr / bc1), b1, b2, eps,
-                       (float)(1.0 / sqrt(bc2)), gscale);
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, hp);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, n, (const float*)hp);
     CHECK_LAUNCH("adam_step");
     return 0;
 }
 
-__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ tgt, const float* __restrict__ src, long n, float decay) {
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ tgt, const float* __restrict__ src, long n,
+                                                  const float* __restrict__ decay_ptr) {
+    const float decay = decay_ptr[0];
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
         tgt[i] = tgt[i] * decay + src[i] * (1.f - decay);
 }
 
-extern "C" int ieagan_ema_update(float* tgt, const float* src, long n, float decay, void* stream) {
+extern "C" int ieagan_ema_update(float* tgt, const float* src, long n, const float* decay, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof("ema_update", 0.0, 12.0 * n, st);
     long blocks = (n + 255) / 256;

@@ -19,9 +19,9 @@ class FusedAdam(torch.optim.Optimizer):
             raise NotImplementedError("FusedAdam: weight_decay=0, amsgrad=False (the reference's settings)")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False))
         self.owner = owner          # the nn.Module whose arena holds exactly these parameters
-        self._m = self._v = None
+        self._m = self._v = self._hp = None
+        self._hp_host = None
         self._step = 0
-        self.grad_scale = 1.0       # folded into the kernel (used for clip_grad_norm_ without an extra pass)
 
     def _arena(self):
         a = self.owner.__dict__.get("_arena")
@@ -38,6 +38,19 @@ class FusedAdam(torch.optim.Optimizer):
             return super().zero_grad(set_to_none=set_to_none)
         self._arena().attach_grads()
 
+    def push_hyper(self):
+        """Mirror lr / betas / eps into the device block the kernel reads (no-op when unchanged); called
+        by ``step`` and, when the train step is replayed from a HIP graph, once per replay."""
+        g = self.param_groups[0]
+        cur = (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]))
+        if self._hp is None:
+            a = self._arena()
+            self._hp = torch.tensor([*cur, float(self._step), 1.0, 0.0, 0.0], dtype=torch.float32, device=a.flat.device)
+            self._hp_host = cur
+        elif cur != self._hp_host:
+            self._hp[0:4] = torch.tensor(cur, dtype=torch.float32)
+            self._hp_host = cur
+
     @torch.no_grad()
     def step(self, closure=None):
         H.require_gpu()
@@ -53,22 +66,23 @@ class FusedAdam(torch.optim.Optimizer):
         if self._m is None or self._m.numel() != n or self._m.device != a.flat.device:
             self._m = torch.zeros(n, dtype=torch.float32, device=a.flat.device)
             self._v = torch.zeros(n, dtype=torch.float32, device=a.flat.device)
-        g = self.param_groups[0]
-        self._step += 1
+        if not torch.cuda.is_current_stream_capturing():
+            self.push_hyper()
+        self._step += 1          # host mirror (informational; the device counter hp[4] is authoritative)
         H.call("ieagan_adam_step", a.flat.data_ptr(), a.grad.data_ptr(), self._m.data_ptr(), self._v.data_ptr(), n,
-               float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), self._step,
-               float(self.grad_scale), H.stream())
-        self.grad_scale = 1.0
+               self._hp.data_ptr(), H.stream())
 
     # checkpoint format: flat moments + step (the reference's per-parameter dict does not survive the
     # arena layout; utils.load_weights accepts both)
     def state_dict(self):
-        return {"fused": True, "step": self._step, "exp_avg": self._m, "exp_avg_sq": self._v,
+        step = int(self._hp[4].item()) if self._hp is not None else self._step
+        return {"fused": True, "step": step, "exp_avg": self._m, "exp_avg_sq": self._v,
                 "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
 
     def load_state_dict(self, sd):
         if not sd.get("fused"):
             raise ValueError("FusedAdam.load_state_dict expects a FusedAdam checkpoint")
         self._step, self._m, self._v = sd["step"], sd["exp_avg"], sd["exp_avg_sq"]
+        self._hp = None
         for g, s in zip(self.param_groups, sd["param_groups"]):
             g.update(s)

@@ -58,8 +58,9 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
         else:
             then()
 
-    def train(x, y, noise=None):
-        """``noise`` (optional, parity tests): {'z_d','rdof_d','aug_d','z_g','rdof_g','aug_g'} replaces the
+    def step(x, y, noise=None):
+        """One D update + one G update; returns the five losses as ONE device tensor (no host sync).
+        ``noise`` (optional, parity tests): {'z_d','rdof_d','aug_d','z_g','rdof_g','aug_g'} replaces the
         draws of the two generator passes; None = sample exactly where the reference samples."""
         import diff_aug as _da
 
@@ -176,8 +177,40 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
             if sync is not None:
                 sync.wait("G")
             ema.update(state_dict["itr"])
+        return torch.stack([v.detach().float().reshape(()) for v in (G_loss, D_loss_real, D_loss_fake, unif_loss_d, iea_loss)])
 
-        vals = torch.stack([v.detach().float().reshape(()) for v in (G_loss, D_loss_real, D_loss_fake, unif_loss_d, iea_loss)]).tolist()
-        return dict(zip(("G_loss", "D_loss_real", "D_loss_fake", "unif_loss_d", "iea_loss"), (float(v) for v in vals)))
+    keys = ("G_loss", "D_loss_real", "D_loss_fake", "unif_loss_d", "iea_loss")
+    graph = {"g": None, "calls": 0, "x": None, "y": None, "out": None}
+    use_graph = bool(config.get("hip_graph", False)) and sync is None
 
+    def train(x, y, noise=None):
+        """The reference's ``train(x, y) -> dict of 5 python floats`` (ONE host sync, at the end).
+
+        With ``config['hip_graph']`` (single-GPU): after two eager warm-up iterations the whole step --
+        both generator passes, three discriminator passes, both backwards, ortho, Adam, EMA: a few thousand
+        launches -- is captured once into a HIP graph and replayed, which removes the Python / launch
+        overhead from the loop.  Everything step-dependent (Adam step counter, lr, EMA decay, RNG offsets)
+        lives in device memory, so the captured graph stays valid."""
+        if not use_graph or noise is not None:
+            return dict(zip(keys, step(x, y, noise).tolist()))
+        if graph["g"] is None:
+            if graph["calls"] < 2:
+                graph["calls"] += 1
+                return dict(zip(keys, step(x, y).tolist()))
+            graph["x"], graph["y"] = x.clone(), y.clone()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                graph["out"] = step(graph["x"], graph["y"])
+            graph["g"] = g
+        graph["x"].copy_(x)
+        graph["y"].copy_(y)
+        for net in (G, D):
+            net.optim.push_hyper()
+        if config["ema"]:
+            ema.push_decay(state_dict["itr"])
+        graph["g"].replay()
+        return dict(zip(keys, graph["out"].tolist()))
+
+    train.step_tensor = step
     return train

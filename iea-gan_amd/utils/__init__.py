@@ -86,6 +86,7 @@ class apply_ema(object):
 
     def __init__(self, source, target, decay=0.9999, start_itr=0):
         self.source, self.target, self.decay, self.start_itr = source, target, decay, start_itr
+        self._decay_dev, self._decay_host = None, None
         print("Initializing EMA parameters to be source parameters...")
         with torch.no_grad():
             tgt = self.target.state_dict()
@@ -105,12 +106,24 @@ class apply_ema(object):
             out.append(a)
         return out
 
-    def update(self, itr=None):
+    def push_decay(self, itr=None):
+        """Mirror the decay for iteration ``itr`` into the device scalar the kernel reads (no-op when
+        unchanged); called by ``update`` and once per replay when the step runs from a HIP graph."""
         decay = 0.0 if (itr and itr < self.start_itr) else self.decay
+        if self._decay_dev is None:
+            self._decay_dev = torch.tensor([decay], dtype=torch.float32, device=next(self.source.parameters()).device)
+        elif decay != self._decay_host:
+            self._decay_dev.fill_(decay)
+        self._decay_host = decay
+
+    def update(self, itr=None):
         H.require_gpu()
         src, tgt = self._arenas()
         assert src.flat.numel() == tgt.flat.numel(), "EMA source / target layouts differ"
-        H.call("ieagan_ema_update", tgt.flat.data_ptr(), src.flat.data_ptr(), src.flat.numel(), float(decay), H.stream())
+        if not torch.cuda.is_current_stream_capturing():
+            self.push_decay(itr)
+        H.call("ieagan_ema_update", tgt.flat.data_ptr(), src.flat.data_ptr(), src.flat.numel(), self._decay_dev.data_ptr(),
+               H.stream())
 
 
 def ortho(model, strength=1e-4, blacklist=None):

@@ -124,9 +124,10 @@ int ieagan_diffaug_bwd(const float* gout, const float* contrast, const long* tx,
                        const long* oy, float* gsums, float* gx, int N, int H, int W, void* stream);
 int ieagan_cr_diffaug(const float* x, const float* flip_u, const long* tx, const long* ty, float* out, int N,
                       int H, int W, void* stream);
-int ieagan_adam_step(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
-                     int step, float gscale, void* stream);
-int ieagan_ema_update(float* tgt, const float* src, long n, float decay, void* stream);
+/* hp: device float[8] = {lr, beta1, beta2, eps, step, grad scale, -, -}; the launcher increments step and
+ * derives the bias corrections on the device, so a captured HIP graph of the step stays valid. */
+int ieagan_adam_step(float* p, const float* g, float* m, float* v, long n, float* hp, void* stream);
+int ieagan_ema_update(float* tgt, const float* src, long n, const float* decay_dev, void* stream);
 
 /* ---- self-test of the transposed LDS read used by conv_wgrad (tests only) ---------------------- */
 int ieagan_selftest_tr_read(const void* in_bf16_64x16, void* out_bf16_64x8, void* stream);

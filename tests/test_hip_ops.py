@@ -365,12 +365,15 @@ def test_adam_and_ema(dev, golden_dir):
     a = np.load(os.path.join(golden_dir, "op_adam.npz"))
     w = torch.from_numpy(a["w0"]).to(dev)
     m, v = torch.zeros_like(w), torch.zeros_like(w)
+    hp = torch.tensor([5e-5, 0.0, 0.999, 1e-6, 0.0, 1.0, 0.0, 0.0], device=dev)   # device-side hyper block, step 0
     for step in range(1, 4):
         gr = torch.from_numpy(a["grads"][step - 1]).to(dev)
-        _hip.call("ieagan_adam_step", w.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), w.numel(), 5e-5, 0.0, 0.999,
-                  1e-6, step, 1.0, _hip.stream())
-    close(w, torch.from_numpy(a["w3"]), 1e-6, "adam (golden)")
+        _hip.call("ieagan_adam_step", w.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), w.numel(), hp.data_ptr(),
+                  _hip.stream())
+    assert float(hp[4]) == 3.0
+    close(w, torch.from_numpy(a["w3"]), 2e-6, "adam (golden)")
     t, s = torch.randn(1000, device=dev), torch.randn(1000, device=dev)
     exp = t * 0.9 + s * 0.1
-    _hip.call("ieagan_ema_update", t.data_ptr(), s.data_ptr(), 1000, 0.9, _hip.stream())
+    dec = torch.tensor([0.9], device=dev)
+    _hip.call("ieagan_ema_update", t.data_ptr(), s.data_ptr(), 1000, dec.data_ptr(), _hip.stream())
     close(t, exp, 1e-6, "ema")
