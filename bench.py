@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP-event timing")
     ap.add_argument("--resolution", type=int, default=256)
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying a HIP graph")
+    ap.add_argument("--shape-tags", action="store_true", help="per-kernel timing split by layer shape (tuning aid)")
     args = ap.parse_args()
 
     import _hip
@@ -161,7 +162,7 @@ def main():
         # same kernels) in eager steps right after the timed region.
         prof_steps = min(args.steps, 3)
         _hip.call("ieagan_prof_reset")
-        _hip.prof_enable(True)
+        _hip.prof_enable(2 if args.shape_tags else 1)
         for _ in range(prof_steps):
             state["itr"] += 1
             train.step_tensor(x, y)
@@ -204,7 +205,7 @@ def main():
         res["roofline"] = roof
         res["kernels"] = [{"name": r["name"], "launches": r["launches"], "ms_per_step": r["ms"] / prof_steps,
                            "tflops": (r["flops"] / (r["ms"] * 1e-3) / 1e12) if r["flops"] else None,
-                           "GBs": (r["bytes"] / (r["ms"] * 1e-3) / 1e9) if r["bytes"] else None} for r in recs[:12]]
+                           "GBs": (r["bytes"] / (r["ms"] * 1e-3) / 1e9) if r["bytes"] else None} for r in recs[:(60 if args.shape_tags else 12)]]
         res["kernel_ms_per_step_total"] = total / prof_steps
         res["kernel_timing"] = ("HIP events around every launch inside the timed region" if eager_timing else
                                 f"HIP events around every launch in {prof_steps} eager steps run right after the timed graph replays")

@@ -38,7 +38,7 @@ class WgradDesc(C.Structure):
 
 
 class ProfRec(C.Structure):
-    _fields_ = [("name", C.c_char * 48), ("launches", C.c_long), ("ms", C.c_double),
+    _fields_ = [("name", C.c_char * 96), ("launches", C.c_long), ("ms", C.c_double),
                 ("flops", C.c_double), ("bytes", C.c_double)]
 
 
@@ -118,12 +118,12 @@ def src_desc(x, Cx, Hs, Ws, rs=0, scale=None, shift=None, nstride=0, relu=False)
     return SrcDesc(ptr(x), Cx, Hs, Ws, rs, ptr(scale), ptr(shift), nstride, int(bool(relu)))
 
 
-def prof_enable(on: bool) -> None:
+def prof_enable(on) -> None:
     call("ieagan_prof_enable", int(on))
 
 
 def prof_collect() -> list:
-    buf = (ProfRec * 64)()
-    n = lib().ieagan_prof_collect(buf, 64)
+    buf = (ProfRec * 512)()
+    n = lib().ieagan_prof_collect(buf, 512)
     return [dict(name=buf[k].name.decode(), launches=buf[k].launches, ms=buf[k].ms, flops=buf[k].flops,
                  bytes=buf[k].bytes) for k in range(n)]

@@ -27,7 +27,7 @@ extern "C" int ieagan_abi_version(void) { return 1; }
 // profiling: when enabled every launcher brackets its launches with two events on its stream
 // ------------------------------------------------------------------------------------------------
 struct ProfEvt {
-    const char* name;
+    std::string name;
     hipEvent_t a, b;
     double flops, bytes;
 };
@@ -35,9 +35,13 @@ static std::mutex g_prof_mu;
 static bool g_prof_on = false;
 static std::vector<ProfEvt> g_prof;
 
-ProfScope::ProfScope(const char* name, double flops, double bytes, hipStream_t s) : slot(-1), stream(s) {
+static bool g_prof_tags = false;
+bool prof_tags_on() { return g_prof_on && g_prof_tags; }
+
+ProfScope::ProfScope(const char* name, double flops, double bytes, hipStream_t s, const char* tag) : slot(-1), stream(s) {
     if (!g_prof_on) return;
-    ProfEvt e{name, nullptr, nullptr, flops, bytes};
+    ProfEvt e{std::string(name), nullptr, nullptr, flops, bytes};
+    if (g_prof_tags && tag != nullptr) e.name += std::string(" ") + tag;
     if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
     hipEventRecord(e.a, s);
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -51,9 +55,10 @@ ProfScope::~ProfScope() {
     hipEventRecord(g_prof[slot].b, stream);
 }
 
-extern "C" int ieagan_prof_enable(int on) {
+extern "C" int ieagan_prof_enable(int on) {      // 0 off, 1 per kernel family, 2 per kernel family + shape tag
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_on = on != 0;
+    g_prof_tags = on == 2;
     return 0;
 }
 
@@ -81,7 +86,7 @@ extern "C" int ieagan_prof_collect(ieagan_prof_rec* out, int cap) {
         auto& r = agg[e.name];
         if (r.launches == 0) {
             memset(&r, 0, sizeof(r));
-            strncpy(r.name, e.name, sizeof(r.name) - 1);
+            strncpy(r.name, e.name.c_str(), sizeof(r.name) - 1);
         }
         r.launches += 1;
         r.ms += ms;

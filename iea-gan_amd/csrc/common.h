@@ -19,11 +19,13 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 void ieagan_set_error(const char* fmt, ...);
 // optional per-kernel event profiling (api.hip); name must be a string literal
 struct ProfScope {
-    ProfScope(const char* name, double flops, double bytes, hipStream_t s);
+    ProfScope(const char* name, double flops, double bytes, hipStream_t s, const char* tag = nullptr);
     ~ProfScope();
     int slot;
     hipStream_t stream;
 };
+
+bool prof_tags_on();
 
 #define CHECK_ARG(cond, ...)                                   \
     do {                                                       \

@@ -14,6 +14,7 @@
 // D[row 4*(l>>4)+r][col l&15].
 #include "common.h"
 #include "conv_args.h"
+#include <stdio.h>
 
 // ------------------------------------------------------------------------------------------------
 // A-operand gather with fused prologue.  Returns 8 consecutive channels [c, c+8) of the (virtual)
@@ -442,7 +443,11 @@ int conv_gather_launch(const ConvArgs& a, hipStream_t st) {
     const double bytes = 2.0 * a.N * ((double)a.src.Hs * a.src.Ws * a.Cin + (double)a.H * a.W * a.Cout);
     const bool halo = a.taps == 9 && a.src.rs != 2 && a.W >= 16 && a.H >= 4 && a.Cin % 16 == 0 && !g_force_gather &&
                       (size_t)(HT_H + 2) * (HT_W + 2) * (a.Cin * 2 + 16) <= 150 * 1024;
-    ProfScope prof(a.taps == 9 ? (halo ? "conv3x3_halo" : "conv3x3_gather") : "conv1x1_gather", flops, bytes, st);
+    char tag[64] = "";
+    if (prof_tags_on())
+        snprintf(tag, sizeof(tag), "ci%d co%d %dx%d rs%d a%d r%d res%d%s", a.Cin, a.Cout, a.H, a.W, a.src.rs, a.src.scale != nullptr,
+                 a.src.relu, a.ra ? a.ra_rs + 1 : 0, a.mask ? " mask" : "");
+    ProfScope prof(a.taps == 9 ? (halo ? "conv3x3_halo" : "conv3x3_gather") : "conv1x1_gather", flops, bytes, st, tag);
     int rc;
     if (halo) {
         rc = (a.src.rs == 0) ? launch_halo_pro<0>(a, st) : launch_halo_pro<1>(a, st);
@@ -624,7 +629,9 @@ int conv_wgrad_launch(const WgradArgs& a0, hipStream_t st, int use_tr) {
     CHECK_ARG(lds <= 160 * 1024, "wgrad: LDS request %zu too large", lds);
     const double flops = 2.0 * a.N * a.H * a.W * (double)a.Cout * a.taps * a.Cin;
     const double bytes = 2.0 * a.N * ((double)a.src.Hs * a.src.Ws * a.Cin + (double)a.H * a.W * a.Cout);
-    ProfScope prof(a.taps == 9 ? "conv3x3_wgrad" : "conv1x1_wgrad", flops, bytes, st);
+    char tag[64] = "";
+    if (prof_tags_on()) snprintf(tag, sizeof(tag), "ci%d co%d %dx%d rs%d grid%dx%dx%d", a.Cin, a.Cout, a.H, a.W, a.src.rs, gx, gy, gz);
+    ProfScope prof(a.taps == 9 ? "conv3x3_wgrad" : "conv1x1_wgrad", flops, bytes, st, tag);
     dim3 grid(gx, gy, gz);
 #define WG_DISPATCH(TR)                                                                  \
     if (a.taps == 9) {                                                                   \

@@ -22,10 +22,10 @@ const char* ieagan_last_error(void);
 int ieagan_abi_version(void);
 
 /* ---- profiling hooks (bench.py): per-kernel HIP-event timing on the launch stream ---- */
-int ieagan_prof_enable(int on);          /* 1: bracket every launch with hipEvents; 0: off     */
+int ieagan_prof_enable(int on);          /* 0 off | 1 time every launch (hipEvents) | 2 + shape tags */
 int ieagan_prof_reset(void);
 /* Writes up to `cap` records {name[48], launches, ms, flops, bytes}; returns the record count.   */
-typedef struct { char name[48]; long launches; double ms; double flops; double bytes; } ieagan_prof_rec;
+typedef struct { char name[96]; long launches; double ms; double flops; double bytes; } ieagan_prof_rec;
 int ieagan_prof_collect(ieagan_prof_rec* out, int cap);
 
 /* ---- source operand of a convolution with its fused prologue --------------------------------
