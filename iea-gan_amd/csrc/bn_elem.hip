@@ -216,37 +216,45 @@ extern "C" int ieagan_prologue_bwd(const void* da, const void* x, int Cx, const 
 //   training: batch statistics + running-stat update (momentum, unbiased variance for the running
 //             update, as F.batch_norm); eval: running statistics
 // ------------------------------------------------------------------------------------------------
-__global__ void bn_finalize_fwd_kernel(const float* __restrict__ stats, float count, const float* __restrict__ gain,
+// one wave per channel: lanes fold the statistics replicas, then fan out over the images
+__global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __restrict__ stats, float count, const float* __restrict__ gain,
                                        const float* __restrict__ bias, int ld, int plus_one, float eps, float momentum,
                                        int training, float* __restrict__ run_mean, float* __restrict__ run_var,
                                        float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_rstd,
                                        int N, int C) {
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
-        float mean, var;
-        if (training) {
-            float s1 = 0.f, s2 = 0.f;
-            for (int r = 0; r < STAT_REPL; ++r) {
-                s1 += stats[(long)r * 2 * C + c];
-                s2 += stats[(long)r * 2 * C + C + c];
-            }
-            mean = s1 / count;
-            var = fmaxf(s2 / count - mean * mean, 0.f);
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    float mean, var;
+    if (training) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int r = lane; r < STAT_REPL; r += 64) {
+            s1 += stats[(long)r * 2 * C + c];
+            s2 += stats[(long)r * 2 * C + C + c];
+        }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        mean = s1 / count;
+        var = fmaxf(s2 / count - mean * mean, 0.f);
+        if (lane == 0) {
             run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
             run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * (count / fmaxf(count - 1.f, 1.f));
-        } else {
-            mean = run_mean[c];
-            var = run_var[c];
         }
-        const float rstd = rsqrtf(var + eps);
+    } else {
+        mean = run_mean[c];
+        var = run_var[c];
+    }
+    const float rstd = rsqrtf(var + eps);
+    if (lane == 0) {
         mean_rstd[c] = mean;
         mean_rstd[C + c] = rstd;
-        const int rows = (ld == 0) ? 1 : N;
-        for (int n = 0; n < rows; ++n) {
-            const float g = gain[(long)n * ld + c] + (plus_one ? 1.f : 0.f);
-            const float s = rstd * g;
-            scale[(long)n * C + c] = s;
-            shift[(long)n * C + c] = bias[(long)n * ld + c] - mean * s;
-        }
+    }
+    const int rows = (ld == 0) ? 1 : N;
+    for (int n = lane; n < rows; n += 64) {
+        const float g = gain[(long)n * ld + c] + (plus_one ? 1.f : 0.f);
+        const float sc = rstd * g;
+        scale[(long)n * C + c] = sc;
+        shift[(long)n * C + c] = bias[(long)n * ld + c] - mean * sc;
     }
 }
 
@@ -257,39 +265,42 @@ extern "C" int ieagan_bn_finalize_fwd(const float* stats, float count, const flo
     CHECK_ARG(!training || stats != nullptr, "bn_finalize: training mode needs batch statistics");
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof("bn_finalize_fwd", 0.0, 0.0, st);
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, stats, count, gain, bias, ld, plus_one, eps,
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, stats, count, gain, bias, ld, plus_one, eps,
                        momentum, training, run_mean, run_var, scale, shift, mean_rstd, N, C);
     CHECK_LAUNCH("bn_finalize_fwd");
     return 0;
 }
 
 //   dscale/dshift [rows][C]  ->  dgain/dbias [rows][ld-strided slice] (ld==0: [C]), dstat [2][C]
-__global__ void bn_finalize_bwd_kernel(const float* __restrict__ dscale, const float* __restrict__ dshift,
+__global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* __restrict__ dscale, const float* __restrict__ dshift,
                                        const float* __restrict__ gain, int ld, int plus_one, const float* __restrict__ mean_rstd,
                                        float count, int training, float* __restrict__ dgain, float* __restrict__ dbias, int ldd,
                                        float* __restrict__ dstat, int N, int C) {
-    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
-        const float mean = mean_rstd[c], rstd = mean_rstd[C + c];
-        const int rows = (ld == 0) ? 1 : N;
-        float drstd = 0.f, dmean = 0.f;
-        for (int n = 0; n < rows; ++n) {
-            const float g = gain[(long)n * ld + c] + (plus_one ? 1.f : 0.f);
-            const float ds = dscale[(long)n * C + c], dt = dshift[(long)n * C + c];
-            const float e = ds - dt * mean;          // d/d(scale) with shift = bias - mean*scale folded in
-            dgain[(long)n * ldd + c] = e * rstd;
-            dbias[(long)n * ldd + c] = dt;
-            drstd += e * g;
-            dmean -= dt * rstd * g;
-        }
-        if (dstat) {
-            if (training) {
-                const float dvar = -0.5f * rstd * rstd * rstd * drstd;
-                dstat[C + c] = dvar / count;                          // d sumsq
-                dstat[c] = (dmean - 2.f * mean * dvar) / count;       // d sum
-            } else {
-                dstat[c] = 0.f;
-                dstat[C + c] = 0.f;
-            }
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    const float mean = mean_rstd[c], rstd = mean_rstd[C + c];
+    const int rows = (ld == 0) ? 1 : N;
+    float drstd = 0.f, dmean = 0.f;
+    for (int n = lane; n < rows; n += 64) {
+        const float g = gain[(long)n * ld + c] + (plus_one ? 1.f : 0.f);
+        const float ds = dscale[(long)n * C + c], dt = dshift[(long)n * C + c];
+        const float e = ds - dt * mean;          // d/d(scale) with shift = bias - mean*scale folded in
+        dgain[(long)n * ldd + c] = e * rstd;
+        dbias[(long)n * ldd + c] = dt;
+        drstd += e * g;
+        dmean -= dt * rstd * g;
+    }
+    drstd = wave_sum(drstd);
+    dmean = wave_sum(dmean);
+    if (dstat && lane == 0) {
+        if (training) {
+            const float dvar = -0.5f * rstd * rstd * rstd * drstd;
+            dstat[C + c] = dvar / count;                          // d sumsq
+            dstat[c] = (dmean - 2.f * mean * dvar) / count;       // d sum
+        } else {
+            dstat[c] = 0.f;
+            dstat[C + c] = 0.f;
         }
     }
 }
@@ -299,7 +310,7 @@ extern "C" int ieagan_bn_finalize_bwd(const float* dscale, const float* dshift, 
                                       int ldd, float* dstat, int N, int C, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof("bn_finalize_bwd", 0.0, 0.0, st);
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, dscale, dshift, gain, ld, plus_one,
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, dscale, dshift, gain, ld, plus_one,
                        mean_rstd, count, training, dgain, dbias, ldd, dstat, N, C);
     CHECK_LAUNCH("bn_finalize_bwd");
     return 0;

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void sn_bwd_inner_kernel(const float* __restri
 
 __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const float* __restrict__ gsn, int kind, int out, int in, int taps, int cin,
                                                            int kpad, const float* __restrict__ ctx, const float* __restrict__ inner,
-                                                           float* __restrict__ dW) {
+                                                           float* __restrict__ dW, int accumulate) {
     const float sigma = ctx[0];
     const float isg = 1.f / sigma;
     const float coef = inner[0] * isg * isg;
@@ -208,21 +208,114 @@ __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const float* __restri
     const long total = (long)out * in;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         const int o = (int)(e / in), i = (int)(e % in);
-        dW[e] = gsn_at(gsn, kind, o, i, out, in, taps, cin, kpad) * isg - coef * u[o] * v[i];
+        const float d = gsn_at(gsn, kind, o, i, out, in, taps, cin, kpad) * isg - coef * u[o] * v[i];
+        dW[e] = accumulate ? dW[e] + d : d;
+    }
+}
+
+// one launch for a whole (small) layer: ordered block reduction of <gsn, W>, then the apply pass, plus
+// the fold of the replicated bias column sums -- replaces memset + 2 kernels + sum(0) + 2 autograd adds
+__global__ __launch_bounds__(1024) void sn_bwd_fused_kernel(const float* __restrict__ gsn, const float* __restrict__ W, int kind, int out,
+                                                            int in, int taps, int cin, int kpad, const float* __restrict__ ctx,
+                                                            float* __restrict__ dW, int accumulate, const float* __restrict__ colsum,
+                                                            float* __restrict__ dbias, int bias_accumulate) {
+    __shared__ float red[16];
+    const long total = (long)out * in;
+    float s = 0.f;
+    for (long e = threadIdx.x; e < total; e += 1024) {
+        const int o = (int)(e / in), i = (int)(e % in);
+        s += gsn_at(gsn, kind, o, i, out, in, taps, cin, kpad) * W[e];
+    }
+    const float inner = block_sum(s, red);
+    const float sigma = ctx[0];
+    const float isg = 1.f / sigma;
+    const float coef = inner * isg * isg;
+    const float* u = ctx + 8;
+    const float* v = ctx + 8 + out + in;
+    for (long e = threadIdx.x; e < total; e += 1024) {
+        const int o = (int)(e / in), i = (int)(e % in);
+        const float d = gsn_at(gsn, kind, o, i, out, in, taps, cin, kpad) * isg - coef * u[o] * v[i];
+        dW[e] = accumulate ? dW[e] + d : d;
+    }
+    if (colsum != nullptr) {
+        const int nb = (kind == 3) ? 1 : out;
+        for (int c = threadIdx.x; c < nb; c += 1024) {
+            float b = 0.f;
+            for (int r = 0; r < STAT_REPL; ++r) b += colsum[r * nb + c];
+            dbias[c] = bias_accumulate ? dbias[c] + b : b;
+        }
+    }
+}
+
+__global__ void bias_fold_kernel(const float* __restrict__ colsum, float* __restrict__ dbias, int nb, int accumulate) {
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < nb; c += gridDim.x * blockDim.x) {
+        float b = 0.f;
+        for (int r = 0; r < STAT_REPL; ++r) b += colsum[r * nb + c];
+        dbias[c] = accumulate ? dbias[c] + b : b;
     }
 }
 
 extern "C" int ieagan_sn_backward(const float* gsn, const float* W, int kind, int out, int in, int taps, int cin, int kpad,
-                                  const float* ctx, float* inner_scratch, float* dW, void* stream) {
+                                  const float* ctx, float* inner_scratch, float* dW, int accumulate, const float* colsum,
+                                  float* dbias, int bias_accumulate, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     CHECK_ARG(kind >= 0 && kind <= 3, "sn_backward: bad kind");
+    CHECK_ARG(colsum == nullptr || dbias != nullptr, "sn_backward: colsum needs dbias");
     ProfScope prof("sn_backward", 0.0, 0.0, st);
-    hipError_t e = hipMemsetAsync(inner_scratch, 0, sizeof(float), st);
-    if (e != hipSuccess) { ieagan_set_error("sn_backward: memset failed"); return IEAGAN_ELAUNCH; }
+    if ((long)out * in <= 20000) {
+        hipLaunchKernelGGL(sn_bwd_fused_kernel, dim3(1), dim3(1024), 0, st, gsn, W, kind, out, in, taps, cin, kpad, ctx, dW, accumulate,
+                           colsum, dbias, bias_accumulate);
+        CHECK_LAUNCH("sn_backward");
+        return 0;
+    }
+    CHECK_ARG(inner_scratch != nullptr, "sn_backward: large layer needs a zeroed scratch float");
     long blocks = ((long)out * in + 255) / 256;
     if (blocks > 512) blocks = 512;
     hipLaunchKernelGGL(sn_bwd_inner_kernel, dim3((unsigned)blocks), dim3(256), 0, st, gsn, W, kind, out, in, taps, cin, kpad, inner_scratch);
-    hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, gsn, kind, out, in, taps, cin, kpad, ctx, (const float*)inner_scratch, dW);
+    hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, gsn, kind, out, in, taps, cin, kpad, ctx,
+                       (const float*)inner_scratch, dW, accumulate);
+    if (colsum != nullptr)
+        hipLaunchKernelGGL(bias_fold_kernel, dim3(cdiv(out, 256)), dim3(256), 0, st, colsum, dbias, kind == 3 ? 1 : out, bias_accumulate);
     CHECK_LAUNCH("sn_backward");
+    return 0;
+}
+
+// every ccbn gain / bias SNLinear of a generator at once: block b handles stack layer b.
+//   gst [sum out][in] gradient w.r.t. the stacked normalised rows; layers[b] = table row of layer b;
+//   dst[b] = element offset of that layer's weight gradient inside grad_base
+__global__ __launch_bounds__(1024) void sn_bwd_stack_kernel(const long* __restrict__ tab, const int* __restrict__ layers,
+                                                            const long* __restrict__ row0, const long* __restrict__ dst,
+                                                            const float* __restrict__ gst, const float* __restrict__ params,
+                                                            const float* __restrict__ ctx, float* __restrict__ grad_base, int accumulate) {
+    __shared__ float red[16];
+    const long* L = tab + (long)layers[blockIdx.x] * SN_FIELDS;
+    const int out = (int)L[F_OUT], in = (int)L[F_IN];
+    const float* W = params + L[F_W];
+    const float* c = ctx + L[F_CTX];
+    const float* g = gst + row0[blockIdx.x] * in;
+    float* dW = grad_base + dst[blockIdx.x];
+    const long total = (long)out * in;
+    float s = 0.f;
+    for (long e = threadIdx.x; e < total; e += 1024) s += g[e] * W[e];
+    const float inner = block_sum(s, red);
+    const float isg = 1.f / c[0];
+    const float coef = inner * isg * isg;
+    const float* u = c + 8;
+    const float* v = c + 8 + out + in;
+    for (long e = threadIdx.x; e < total; e += 1024) {
+        const int o = (int)(e / in), i = (int)(e % in);
+        const float d = g[e] * isg - coef * u[o] * v[i];
+        dW[e] = accumulate ? dW[e] + d : d;
+    }
+}
+
+extern "C" int ieagan_sn_backward_stack(const long* tab, const int* layers, const long* row0, const long* dst, int nlayers,
+                                        const float* gst, const float* params, const float* ctx, float* grad_base, int accumulate,
+                                        void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (nlayers <= 0) return 0;
+    ProfScope prof("sn_backward_stack", 0.0, 0.0, st);
+    hipLaunchKernelGGL(sn_bwd_stack_kernel, dim3(nlayers), dim3(1024), 0, st, tab, layers, row0, dst, gst, params, ctx, grad_base, accumulate);
+    CHECK_LAUNCH("sn_backward_stack");
     return 0;
 }

@@ -214,8 +214,18 @@ class Generator(nn.Module):
             cols.append(cmap)
         bank = ops.SNBank(ar.flat, entries, stack=stack)
         modmap = dict(_sn_children(self, ""))
-        self._plan = dict(arena=ar, bank=bank, stack=stack, cols=cols, stack_weights=[modmap[n].weight for n in stack],
-                          n_bn=4 * len(self.blocks))
+        sw = [modmap[n].weight for n in stack]
+        offs = {id(p): o for p, o, _ in ar.param_slices}
+        dev = ar.flat.device
+        rows, r0 = [], 0
+        for w in sw:
+            rows.append(r0)
+            r0 += w.shape[0]
+        self._plan = dict(arena=ar, bank=bank, stack=stack, cols=cols, stack_weights=sw, n_bn=4 * len(self.blocks),
+                          stack_layers=torch.tensor([bank.index[n] for n in stack], dtype=torch.int32, device=dev),
+                          stack_row0=torch.tensor(rows, dtype=torch.int64, device=dev),
+                          stack_dst_arena=torch.tensor([offs[id(w)] for w in sw], dtype=torch.int64, device=dev),
+                          stack_dst_flat=torch.tensor([r * sw[0].shape[1] for r in rows], dtype=torch.int64, device=dev))
         return self._plan
 
     def forward(self, z, y, rdof=None):
@@ -230,7 +240,7 @@ class Generator(nn.Module):
         ye = self.linear_f.fused(torch.cat([ye, rdof], 1), recs["linear_f"])
         ye = self.RR_G(ye.unsqueeze(0)).squeeze(0)
         zc = torch.cat([ye, z], 1)
-        gb = ops.StackedSNLinearFn.apply(zc, recs["__stack__"], recs, plan["stack"], *plan["stack_weights"])
+        gb = ops.StackedSNLinearFn.apply(zc, recs["__stack__"], recs, plan, *plan["stack_weights"])
         bank = ops.GainBank(gb, plan["n_bn"])
         h = self.linear.fused(zc, recs["linear"])
         h = h.view(N, -1, self.bottom_width, self.bottom_width * self.H_base)

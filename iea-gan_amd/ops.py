@@ -27,8 +27,57 @@ def _kpad(k: int) -> int:
     return (k + 31) // 32 * 32
 
 
+class _ZeroPool:
+    """Zero-initialised fp32 scratch carved from a few large pre-filled chunks: the step needs ~900 small
+    zeroed buffers (statistics replicas, column sums, split-K accumulators); one fill per 32 MiB chunk
+    replaces one fill kernel per buffer.  A chunk is used once; it is released when its views die."""
+    CHUNK = 8 << 20            # floats
+
+    def __init__(self):
+        self.buf, self.pos = {}, {}
+
+    def take(self, n: int, device) -> torch.Tensor:
+        key = str(device)
+        n_al = (n + 63) // 64 * 64
+        if n_al > self.CHUNK // 4:
+            return torch.zeros(n, dtype=torch.float32, device=device)
+        if key not in self.buf or self.pos[key] + n_al > self.buf[key].numel():
+            self.buf[key] = torch.zeros(self.CHUNK, dtype=torch.float32, device=device)
+            self.pos[key] = 0
+        o = self.pos[key]
+        self.pos[key] = o + n_al
+        return self.buf[key][o:o + n]
+
+
+_ZEROS = _ZeroPool()
+
+
+def zeros(shape, device) -> torch.Tensor:
+    """fp32 zeros of ``shape`` from the pool."""
+    n = 1
+    for d in (shape if isinstance(shape, (tuple, list, torch.Size)) else (shape,)):
+        n *= int(d)
+    return _ZEROS.take(n, device).view(shape)
+
+
 def new_stats(C: int, device) -> torch.Tensor:
-    return torch.zeros(STAT_REPL, 2, C, dtype=torch.float32, device=device)
+    return zeros((STAT_REPL, 2, C), device)
+
+
+# When True (set by the train step around ``backward()``), gradients of spectrally normalised weights
+# and of conv biases are accumulated by the HIP kernels straight into the existing ``param.grad`` (views
+# of the flat gradient arena) and autograd is handed ``None`` -- no per-parameter accumulate kernels.
+DIRECT_GRADS = False
+
+
+class direct_grads:
+    def __enter__(self):
+        global DIRECT_GRADS
+        self.prev, DIRECT_GRADS = DIRECT_GRADS, True
+
+    def __exit__(self, *a):
+        global DIRECT_GRADS
+        DIRECT_GRADS = self.prev
 
 
 # =====================================================================================================
@@ -134,6 +183,7 @@ class SNBank:
             else:
                 r.w_plain = pack[p1:p1 + out * inn * 4].view(torch.float32)      # [9][C]
             recs[n] = r
+        recs["__ctx__"] = ctx
         if self.stack_total:
             first = self.meta[self.index[next(iter(self.stack_rows))]]
             inn = first[2]
@@ -141,13 +191,27 @@ class SNBank:
         return recs
 
 
-def sn_backward(gsn: torch.Tensor, weight: torch.Tensor, rec: SNRecord) -> torch.Tensor:
-    """dW (parameter layout) from the gradient w.r.t. the normalised weight (consumer layout)."""
-    dW = torch.empty_like(weight)
-    scratch = torch.empty(1, dtype=torch.float32, device=weight.device)
+def _direct_target(p):
+    g = p.grad if (DIRECT_GRADS and p is not None) else None
+    return g if (g is not None and g.is_contiguous() and g.dtype == torch.float32) else None
+
+
+def sn_backward(gsn: torch.Tensor, weight: torch.Tensor, rec: SNRecord, colsum=None, bias=None):
+    """Gradient of the parameter ``weight`` from the gradient w.r.t. its normalised form (consumer layout),
+    plus (optionally) the bias gradient folded from replicated column sums.  Returns (dW, dbias); an entry is
+    None when it was accumulated directly into ``param.grad`` (see DIRECT_GRADS)."""
+    tgt = _direct_target(weight)
+    dW = tgt if tgt is not None else torch.empty_like(weight)
+    btgt = _direct_target(bias) if colsum is not None else None
+    dbias = None
+    if colsum is not None:
+        dbias = btgt if btgt is not None else torch.empty_like(bias)
+    big = rec.out * rec.inn > 20000          # multi-block path: <gsn, W> accumulates into a zeroed scratch float
+    scratch = zeros((1,), weight.device) if big else None
     H.call("ieagan_sn_backward", gsn.data_ptr(), weight.data_ptr(), rec.kind, rec.out, rec.inn, rec.taps, rec.cin,
-           rec.kpad, rec.ctx.data_ptr(), scratch.data_ptr(), dW.data_ptr(), H.stream())
-    return dW
+           rec.kpad, rec.ctx.data_ptr(), H.ptr(scratch), dW.data_ptr(), int(tgt is not None), H.ptr(colsum), H.ptr(dbias),
+           int(btgt is not None), H.stream())
+    return (None if tgt is not None else dW), (None if (btgt is not None or colsum is None) else dbias)
 
 
 class SNWeightFn(torch.autograd.Function):
@@ -162,29 +226,39 @@ class SNWeightFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (weight,) = ctx.saved_tensors
-        return sn_backward(g.contiguous().float(), weight, ctx.rec), None
+        return sn_backward(g.contiguous().float(), weight, ctx.rec)[0], None
 
 
 class StackedSNLinearFn(torch.autograd.Function):
-    """All ccbn gain/bias SNLinear layers of G as ONE GEMM: [N, cond] x [cond, sum C]."""
+    """All ccbn gain/bias SNLinear layers of G as ONE GEMM: [N, cond] x [cond, sum C]; the backward through
+    the 96 spectral norms is one launch (block per layer)."""
 
     @staticmethod
-    def forward(ctx, y, wstack, recs, names, *weights):
-        ctx.recs, ctx.names = recs, names
+    def forward(ctx, y, wstack, recs, plan, *weights):
+        ctx.recs, ctx.plan = recs, plan
         ctx.save_for_backward(y, wstack, *weights)
         return y @ wstack.t()
 
     @staticmethod
     def backward(ctx, g):
         y, wstack, *weights = ctx.saved_tensors
+        plan, recs = ctx.plan, ctx.recs
+        bank, ar = plan["bank"], plan["arena"]
         dy = g @ wstack
-        gst = g.t() @ y                                   # [sum C, cond] gradient w.r.t. normalised rows
-        grads, r0 = [], 0
-        for n, w in zip(ctx.names, weights):
-            rec = ctx.recs[n]
-            grads.append(sn_backward(gst[r0:r0 + rec.out], w, rec))
-            r0 += rec.out
-        return (dy, None, None, None, *grads)
+        gst = (g.t() @ y).contiguous()                    # [sum C, cond] gradient w.r.t. the normalised rows
+        direct = DIRECT_GRADS and ar.grads_attached()
+        if direct:
+            base, dst, out = ar.grad, plan["stack_dst_arena"], [None] * len(weights)
+        else:
+            base, dst = torch.empty_like(gst), plan["stack_dst_flat"]
+            out, r0 = [], 0
+            for w in weights:
+                out.append(base[r0:r0 + w.shape[0]])
+                r0 += w.shape[0]
+        H.call("ieagan_sn_backward_stack", bank.table.data_ptr(), plan["stack_layers"].data_ptr(), plan["stack_row0"].data_ptr(),
+               dst.data_ptr(), len(weights), gst.data_ptr(), bank.arena.data_ptr(), recs["__ctx__"].data_ptr(), base.data_ptr(),
+               int(direct), H.stream())
+        return (dy, None, None, None, *out)
 
 
 # =====================================================================================================
@@ -200,7 +274,7 @@ class GainBank:
 
     def grad_buffer(self):
         if self.grad is None:
-            self.grad = torch.zeros_like(self.gb)
+            self.grad = zeros(self.gb.shape, self.gb.device)
         return self.grad
 
 
@@ -328,6 +402,7 @@ class ConvFn(torch.autograd.Function):
         ctx.ra_shape = ra.shape if ra is not None else None
         ctx.has = (bias is not None, scale is not None, ra is not None, rb is not None)
         ctx.links = (res_out, res_in)
+        ctx.bias_ref = bias
         ctx.save_for_backward(x, weight, scale, shift, out if want_stats else None)
         return out, stats
 
@@ -348,15 +423,13 @@ class ConvFn(torch.autograd.Function):
         dbias = None
         if dstats is not None:
             geff = torch.empty_like(g)
-            colsum = torch.zeros(STAT_REPL, Cout, dtype=torch.float32, device=dev) if has_bias else None
+            colsum = zeros((STAT_REPL, Cout), dev) if has_bias else None
             H.call("ieagan_effgrad", g.data_ptr(), out.data_ptr(), dstats[0].contiguous().data_ptr(), geff.data_ptr(),
                    H.ptr(colsum), P, Cout, H.stream())
             g = geff
         elif has_bias and need[2]:
-            colsum = torch.zeros(STAT_REPL, Cout, dtype=torch.float32, device=dev)
+            colsum = zeros((STAT_REPL, Cout), dev)
             H.call("ieagan_effgrad", g.data_ptr(), None, None, None, colsum.data_ptr(), P, Cout, H.stream())
-        if has_bias and need[2]:
-            dbias = colsum.sum(0)
         # ---- residual operands
         d_ra = d_rb = None
         if has_ra and need[5]:
@@ -408,8 +481,8 @@ class ConvFn(torch.autograd.Function):
                 else:
                     dx = torch.empty(N, Hs, Ws, Cin, dtype=BF16, device=dev)
                     if has_aff:
-                        dscale = torch.zeros_like(scale)
-                        dshift = torch.zeros_like(shift)
+                        dscale = zeros(scale.shape, dev)
+                        dshift = zeros(shift.shape, dev)
                     rmode = 0
                     if res_in is not None:
                         if lmode == 2:
@@ -421,11 +494,13 @@ class ConvFn(torch.autograd.Function):
         # ---- weight gradient (skipped entirely when the parameter is frozen, e.g. D in the G phase)
         dW = None
         if need[1]:
-            dwp = torch.zeros(Cout, rec.kpad, dtype=torch.float32, device=dev)
+            dwp = zeros((Cout, rec.kpad), dev)
             d = H.WgradDesc(N, Hc, Wc, Cin, Cout, taps, rec.kpad,
                             H.src_desc(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu), g.data_ptr(), Cout, dwp.data_ptr(), 0)
             H.call("ieagan_conv_wgrad", d, int(USE_TR_READ), H.stream())
-            dW = sn_backward(dwp, weight, rec)
+            dW, dbias = sn_backward(dwp, weight, rec, colsum if (has_bias and need[2]) else None, ctx.bias_ref)
+        elif has_bias and need[2]:
+            dbias = colsum.sum(0)
         return dx, dW, dbias, dscale, dshift, d_ra, d_rb, None, None, None, None, None, None, None, None, None
 
 
@@ -448,7 +523,7 @@ class InputConvFn(torch.autograd.Function):
         out = torch.empty(N, Hh, Ww, C, dtype=BF16, device=img.device)
         H.call("ieagan_conv_1toC", img.data_ptr(), None, rec.w_plain.data_ptr(), H.ptr(bias), out.data_ptr(), N, Hh, Ww, C, 0,
                H.stream())
-        ctx.rec = rec
+        ctx.rec, ctx.bias_ref = rec, bias
         ctx.save_for_backward(img, weight)
         return out
 
@@ -461,20 +536,21 @@ class InputConvFn(torch.autograd.Function):
         dev = img.device
         g = dout.contiguous()
         need = ctx.needs_input_grad
-        dimg = dW = dbias = None
+        dimg = dW = dbias = colsum = None
         if need[2]:
-            colsum = torch.zeros(STAT_REPL, C, dtype=torch.float32, device=dev)
+            colsum = zeros((STAT_REPL, C), dev)
             H.call("ieagan_effgrad", g.data_ptr(), None, None, None, colsum.data_ptr(), N * Hh * Ww, C, H.stream())
-            dbias = colsum.sum(0)
         if need[0]:
             dimg = torch.empty(N, 1, Hh, Ww, dtype=torch.float32, device=dev)
             H.call("ieagan_conv_Cto1", g.data_ptr(), None, None, 0, 0, rec.w_plain.data_ptr(), None, dimg.data_ptr(), 0, N, Hh,
                    Ww, C, 1, H.stream())
         if need[1]:
-            dw = torch.zeros(9, C, dtype=torch.float32, device=dev)
+            dw = zeros((9, C), dev)
             H.call("ieagan_wgrad_c1", img.data_ptr(), None, g.data_ptr(), None, None, 0, 0, dw.data_ptr(), N, Hh, Ww, C, 0,
                    H.stream())
-            dW = sn_backward(dw, weight, rec)
+            dW, dbias = sn_backward(dw, weight, rec, colsum, ctx.bias_ref)
+        elif colsum is not None:
+            dbias = colsum.sum(0)
         return dimg, dW, dbias, None
 
 
@@ -507,14 +583,14 @@ class OutputConvFn(torch.autograd.Function):
             H.call("ieagan_conv_1toC", dpre.data_ptr(), None, rec.w_plain.data_ptr(), None, da.data_ptr(), N, Hh, Ww, C, 1,
                    H.stream())
             dh = torch.empty_like(h)
-            dscale, dshift = torch.zeros_like(scale), torch.zeros_like(shift)
+            dscale, dshift = zeros(scale.shape, dev), zeros(shift.shape, dev)
             H.call("ieagan_prologue_bwd", da.data_ptr(), h.data_ptr(), C, scale.data_ptr(), shift.data_ptr(), 0, 1, 0,
                    dh.data_ptr(), dscale.data_ptr(), dshift.data_ptr(), N, Hh, Ww, C, None, 0, 0, 0, H.stream())
         if need[3]:
-            dw = torch.zeros(9, C, dtype=torch.float32, device=dev)
+            dw = zeros((9, C), dev)
             H.call("ieagan_wgrad_c1", dpre.data_ptr(), None, h.data_ptr(), scale.data_ptr(), shift.data_ptr(), 0, 1, dw.data_ptr(),
                    N, Hh, Ww, C, 1, H.stream())
-            dW = sn_backward(dw, weight, rec)
+            dW = sn_backward(dw, weight, rec)[0]
         return dh, dscale, dshift, dW, dbias, None
 
 
@@ -586,7 +662,7 @@ class DiffAugFn(torch.autograd.Function):
         N, C, Hh, Ww = x.shape
         x = x.contiguous()
         out = torch.empty_like(x)
-        sums = torch.zeros(N, dtype=torch.float32, device=x.device)
+        sums = zeros((N,), x.device)
         H.call("ieagan_diffaug_fwd", x.data_ptr(), bright.data_ptr(), contrast.data_ptr(), tx.data_ptr(), ty.data_ptr(),
                ox.data_ptr(), oy.data_ptr(), sums.data_ptr(), out.data_ptr(), N, Hh, Ww, H.stream())
         ctx.save_for_backward(contrast, tx, ty, ox, oy)
@@ -598,7 +674,7 @@ class DiffAugFn(torch.autograd.Function):
         N, C, Hh, Ww = g.shape
         g = g.contiguous()
         gx = torch.empty_like(g)
-        gs = torch.zeros(N, dtype=torch.float32, device=g.device)
+        gs = zeros((N,), g.device)
         H.call("ieagan_diffaug_bwd", g.data_ptr(), contrast.data_ptr(), tx.data_ptr(), ty.data_ptr(), ox.data_ptr(),
                oy.data_ptr(), gs.data_ptr(), gx.data_ptr(), N, Hh, Ww, H.stream())
         return gx, None, None, None, None, None, None

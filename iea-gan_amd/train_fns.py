@@ -17,6 +17,7 @@ from __future__ import annotations
 import torch
 
 import loss
+import ops
 import parallel
 import utils
 from cr_diff_aug import CR_DiffAug
@@ -127,7 +128,8 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
                 if contra and config["Uniformity_loss"]:
                     unif_loss_d = loss.unif_loss(cls_embed_real)
                     D_loss = D_loss + config["unif_lambda"] * unif_loss_d
-                (D_loss / float(config["num_D_accumulations"])).backward()
+                with ops.direct_grads():
+                    (D_loss / float(config["num_D_accumulations"])).backward()
             if config["D_ortho"] > 0.0:
                 utils.ortho(D, config["D_ortho"])
             finish(D, "D", config["clip_norm"], True)
@@ -158,7 +160,8 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
                             diff_aug=config["diff_aug"])
                 G_loss = loss.loss_hinge_gen(D_fake)
             G_loss = G_loss / float(config["num_G_accumulations"])
-            G_loss.backward()
+            with ops.direct_grads():
+                G_loss.backward()
             counter += 1
 
         if config["G_ortho"] > 0.0:

@@ -114,8 +114,13 @@ int ieagan_wgrad_c1(const float* img, const float* tanh_y, const void* t, const 
 /* ---- batched spectral norm (sn.hip): layers.SN.W_ / power_iteration (layers.py:89-165) -------- */
 int ieagan_sn_forward(const long* table, const int* blocks, int nblocks, const int* cblocks, int ncblocks,
                       float* params, float* ctx, float* part, void* pack, float eps, int training, void* stream);
+/* dW (=|+=) d(W/sigma) applied to gsn; optionally dbias (=|+=) fold of the replicated column sums */
 int ieagan_sn_backward(const float* gsn, const float* W, int kind, int out, int in, int taps, int cin, int kpad,
-                       const float* ctx, float* inner_scratch, float* dW, void* stream);
+                       const float* ctx, float* inner_scratch, float* dW, int accumulate, const float* colsum,
+                       float* dbias, int bias_accumulate, void* stream);
+int ieagan_sn_backward_stack(const long* table, const int* layers, const long* row0, const long* dst, int nlayers,
+                             const float* gst, const float* params, const float* ctx, float* grad_base, int accumulate,
+                             void* stream);
 
 /* ---- augmentation + optimiser (aug_optim.hip) -------------------------------------------------- */
 int ieagan_diffaug_fwd(const float* x, const float* bright, const float* contrast, const long* tx, const long* ty,

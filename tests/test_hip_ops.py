@@ -109,7 +109,7 @@ def test_sn_forward_backward(dev, out_f, in_shape):
         g = torch.randn(out_f, inn, device=dev)
         g_param = g.view(W.shape)
     (ref,) = torch.autograd.grad(Wsn, [W], g_param)
-    got = ops.sn_backward(g.contiguous(), Wv, rec)
+    got = ops.sn_backward(g.contiguous(), Wv, rec)[0]
     close(got, ref, 1e-4, "sn backward")
 
 
