@@ -65,6 +65,8 @@ _SIGS = {
     "ieagan_sn_forward": [vp, vp, i, vp, i, vp, vp, vp, vp, f, i, vp],
     "ieagan_sn_backward": [vp, vp, i, i, i, i, i, i, vp, vp, vp, i, vp, vp, i, vp],
     "ieagan_sn_backward_stack": [vp, vp, vp, vp, i, vp, vp, vp, vp, i, vp],
+    "ieagan_nl_attention_fwd": [vp, vp, vp, vp, vp, i, i, i, i, i, vp],
+    "ieagan_nl_attention_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, vp],
     "ieagan_diffaug_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, vp],
     "ieagan_diffaug_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, vp],
     "ieagan_cr_diffaug": [vp, vp, vp, vp, vp, i, i, i, vp],

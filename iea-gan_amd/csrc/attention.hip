@@ -1,0 +1,333 @@
+// Non-local (SAGAN-style) self-attention core of the discriminator, streaming softmax on MFMA:
+//   beta = softmax_k(theta_q . phi_k),  o_q = sum_k beta_qk g_k          (layers.py:283-300)
+// with Lq = H*W queries (3072), Lk = H*W/4 max-pooled keys (768), d_qk = C/8 (32), d_v = C/2 (128), no
+// 1/sqrt(d) scaling.  The reference materialises beta [40, 3072, 768] (377 MB fp32); here a workgroup of
+// 4 waves owns 64 queries (forward, dQ) or 64 keys (dK/dV) and streams the other side in chunks of 32, so
+// beta only ever exists as MFMA fragments.
+//
+// Layout trick used by all three kernels: the score tile is computed TRANSPOSED (keys on the MFMA rows for
+// forward/dQ, queries on the rows for dK/dV), so that the accumulator a lane holds -- 4 consecutive "k"
+// indices for ONE column -- is, after bf16 packing, directly the A fragment of the next MFMA (whose k slots
+// are assigned to those indices in the same permuted order), and the matching B fragment is fetched from an
+// LDS-staged natural-layout tile with ds_read_b64_tr_b16.  No shuffles, no LDS round trip for P / dS.
+// k-slot (g, j) of a 32-deep MFMA step  <->  chunk row  pi(g, j) = 4g + j (j < 4) | 16 + 4g + (j - 4).
+#include "common.h"
+
+#define AT_CH 32        // chunk of the streamed side
+
+__device__ __forceinline__ bf16x8 pack2(const f32x4& a, const f32x4& b) {
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        o[j] = f2bf(a[j]);
+        o[4 + j] = f2bf(b[j]);
+    }
+    return o;
+}
+
+// B fragment for k-slots pi(g, .) and columns [c0, c0+16) of an LDS tile [rows][stride] (bf16, natural layout)
+__device__ __forceinline__ bf16x8 trfrag(const bf16* tile, int stride, int c0, int lr, int lg) {
+    const int q = lr >> 2, p = lr & 3;
+    const bf16* p0 = tile + (4 * lg + q) * stride + c0 + 4 * p;
+    const bf16* p1 = p0 + 16 * stride;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)p0);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)p1);
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+
+// 8 consecutive features [8g, 8g+8) of row `row` of a [rows][width] bf16 matrix (zero beyond rows / width)
+__device__ __forceinline__ bf16x8 rowfrag(const bf16* base, long row, long rows, int width, int lg) {
+    if (row >= rows || 8 * lg >= width) return zero8();
+    return *(const bf16x8*)(base + row * width + 8 * lg);
+}
+
+// stage `nrows` (<= 32) rows x width of a row-major bf16 matrix into LDS (zero fill beyond `rows`)
+__device__ __forceinline__ void stage_rows(bf16* lds, const bf16* base, long row0, long rows, int width) {
+    const int chunks = width >> 3;
+    for (int idx = threadIdx.x; idx < AT_CH * chunks; idx += 256) {
+        const int r = idx / chunks, c = idx - r * chunks;
+        bf16x8 v = zero8();
+        if (row0 + r < rows) v = *(const bf16x8*)(base + (row0 + r) * width + c * 8);
+        *(bf16x8*)(lds + r * width + c * 8) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward: O[q] = softmax(Q K^T) V, LSE[q] = log sum exp.  grid (ceil(Lq/64), N), 4 waves x 16 queries.
+// ------------------------------------------------------------------------------------------------
+template <int DV>
+__global__ __launch_bounds__(256) void nl_attn_fwd_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+                                                          const bf16* __restrict__ V, bf16* __restrict__ O, float* __restrict__ LSE,
+                                                          int Lq, int Lk, int dqk) {
+    __shared__ __attribute__((aligned(16))) bf16 vlds[AT_CH * DV];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 15, lg = lane >> 4;
+    const long n = blockIdx.y;
+    const long q0 = (long)blockIdx.x * 64 + wave * 16;
+    const bf16* Qn = Q + n * Lq * dqk;
+    const bf16* Kn = K + n * Lk * dqk;
+    const bf16* Vn = V + n * Lk * DV;
+    const bf16x8 qf = rowfrag(Qn, q0 + lr, Lq, dqk, lg);          // B operand: [d 8g+j][query lr]
+    float m = -1e30f, l = 0.f;
+    f32x4 o[DV / 16];
+#pragma unroll
+    for (int nt = 0; nt < DV / 16; ++nt) o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kc = 0; kc < Lk; kc += AT_CH) {
+        __syncthreads();
+        stage_rows(vlds, Vn, kc, Lk, DV);
+        __syncthreads();
+        f32x4 s[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {                              // S^T tile t: rows = keys kc+16t.., cols = queries
+            const bf16x8 kf = rowfrag(Kn, kc + 16 * t + lr, Lk, dqk, lg);
+            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        }
+        float cm = -1e30f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (kc + 16 * t + 4 * lg + r >= Lk) s[t][r] = -1e30f;
+                cm = fmaxf(cm, s[t][r]);
+            }
+        cm = fmaxf(cm, __shfl_xor(cm, 16, 64));
+        cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
+        const float mn = fmaxf(m, cm);
+        const float alpha = __expf(m - mn);
+        float cs = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[t][r] = __expf(s[t][r] - mn);
+                cs += s[t][r];
+            }
+        cs += __shfl_xor(cs, 16, 64);
+        cs += __shfl_xor(cs, 32, 64);
+        l = l * alpha + cs;
+        m = mn;
+        float ar[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, 4 * lg + r, 64);   // output rows of this lane are queries 4g+r
+        const bf16x8 pa = pack2(s[0], s[1]);                       // A operand: [query lr][k-slot (g,j) = key pi(g,j)]
+#pragma unroll
+        for (int nt = 0; nt < DV / 16; ++nt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[nt][r] *= ar[r];
+            o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, trfrag(vlds, DV, nt * 16, lr, lg), o[nt], 0, 0, 0);
+        }
+    }
+    if (lg == 0 && q0 + lr < Lq) LSE[n * Lq + q0 + lr] = m + __logf(l);
+    float il[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) il[r] = 1.f / __shfl(l, 4 * lg + r, 64);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const long q = q0 + 4 * lg + r;
+        if (q >= Lq) continue;
+#pragma unroll
+        for (int nt = 0; nt < DV / 16; ++nt) O[(n * Lq + q) * DV + nt * 16 + lr] = f2bf(o[nt][r] * il[r]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, query side: delta[q] = dO[q].O[q];  dQ[q] = sum_k dS[q,k] K[k],  dS = P (dP - delta), dP = dO V^T.
+// ------------------------------------------------------------------------------------------------
+template <int DV>
+__global__ __launch_bounds__(256) void nl_attn_bwd_q_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+                                                            const bf16* __restrict__ V, const bf16* __restrict__ O,
+                                                            const bf16* __restrict__ dO, const float* __restrict__ LSE,
+                                                            float* __restrict__ delta, bf16* __restrict__ dQ, int Lq, int Lk, int dqk) {
+    __shared__ __attribute__((aligned(16))) bf16 klds[AT_CH * 32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 15, lg = lane >> 4;
+    const long n = blockIdx.y;
+    const long q0 = (long)blockIdx.x * 64 + wave * 16;
+    const bf16* Qn = Q + n * Lq * dqk;
+    const bf16* Kn = K + n * Lk * dqk;
+    const bf16* Vn = V + n * Lk * DV;
+    const bf16x8 qf = rowfrag(Qn, q0 + lr, Lq, dqk, lg);
+    bf16x8 dof[DV / 32];                                           // dO^T as B operand: [dv 32s+8g+j][query lr]
+    float dl = 0.f;
+#pragma unroll
+    for (int s = 0; s < DV / 32; ++s) {
+        dof[s] = zero8();
+        if (q0 + lr < Lq) {
+            dof[s] = *(const bf16x8*)(dO + (n * Lq + q0 + lr) * DV + 32 * s + 8 * lg);
+            const bf16x8 ov = *(const bf16x8*)(O + (n * Lq + q0 + lr) * DV + 32 * s + 8 * lg);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dl += bf2f(dof[s][j]) * bf2f(ov[j]);
+        }
+    }
+    dl += __shfl_xor(dl, 16, 64);
+    dl += __shfl_xor(dl, 32, 64);                                  // delta of query lr
+    const float lse = (q0 + lr < Lq) ? LSE[n * Lq + q0 + lr] : 0.f;
+    if (lg == 0 && q0 + lr < Lq) delta[n * Lq + q0 + lr] = dl;
+    f32x4 dq[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    for (int kc = 0; kc < Lk; kc += AT_CH) {
+        __syncthreads();
+        {   // K chunk [32 keys][32] (zero padded beyond dqk) for the transposed reads of the dQ product
+            for (int idx = threadIdx.x; idx < AT_CH * 4; idx += 256) {
+                const int r = idx >> 2, c = idx & 3;
+                bf16x8 v = zero8();
+                if (kc + r < Lk && c * 8 < dqk) v = *(const bf16x8*)(Kn + (long)(kc + r) * dqk + c * 8);
+                *(bf16x8*)(klds + r * 32 + c * 8) = v;
+            }
+        }
+        __syncthreads();
+        f32x4 p[2], dp[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const long krow = kc + 16 * t + lr;
+            const bf16x8 kf = rowfrag(Kn, krow, Lk, dqk, lg);
+            p[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            dp[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < DV / 32; ++s) {                    // dP^T tile: rows = keys, cols = queries
+                bf16x8 vf = zero8();
+                if (krow < Lk) vf = *(const bf16x8*)(Vn + krow * DV + 32 * s + 8 * lg);
+                dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[s], dp[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = kc + 16 * t + 4 * lg + r < Lk;
+                const float pr = ok ? __expf(p[t][r] - lse) : 0.f;
+                p[t][r] = pr * (dp[t][r] - dl);                    // dS[query lr][key]
+            }
+        }
+        const bf16x8 dsa = pack2(p[0], p[1]);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+            dq[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsa, trfrag(klds, 32, nt * 16, lr, lg), dq[nt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const long q = q0 + 4 * lg + r;
+        if (q >= Lq) continue;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+            if (nt * 16 + lr < dqk) dQ[(n * Lq + q) * dqk + nt * 16 + lr] = f2bf(dq[nt][r]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, key side: dV[k] = sum_q P[q,k] dO[q],  dK[k] = sum_q dS[q,k] Q[q].  4 waves x 16 keys, queries streamed.
+// ------------------------------------------------------------------------------------------------
+template <int DV>
+__global__ __launch_bounds__(256) void nl_attn_bwd_k_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+                                                            const bf16* __restrict__ V, const bf16* __restrict__ dO,
+                                                            const float* __restrict__ LSE, const float* __restrict__ delta,
+                                                            bf16* __restrict__ dK, bf16* __restrict__ dV, int Lq, int Lk, int dqk) {
+    __shared__ __attribute__((aligned(16))) bf16 dolds[AT_CH * DV];
+    __shared__ __attribute__((aligned(16))) bf16 qlds[AT_CH * 32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 15, lg = lane >> 4;
+    const long n = blockIdx.y;
+    const long k0 = (long)blockIdx.x * 64 + wave * 16;
+    const bf16* Qn = Q + n * Lq * dqk;
+    const bf16* Kn = K + n * Lk * dqk;
+    const bf16* Vn = V + n * Lk * DV;
+    const bf16* dOn = dO + n * Lq * DV;
+    const bf16x8 kf = rowfrag(Kn, k0 + lr, Lk, dqk, lg);          // B operand of S: [d 8g+j][key lr]
+    bf16x8 vf[DV / 32];                                            // V^T as B operand of dP: [dv][key lr]
+#pragma unroll
+    for (int s = 0; s < DV / 32; ++s) {
+        vf[s] = zero8();
+        if (k0 + lr < Lk) vf[s] = *(const bf16x8*)(Vn + (k0 + lr) * DV + 32 * s + 8 * lg);
+    }
+    f32x4 dv[DV / 16], dk[2];
+#pragma unroll
+    for (int nt = 0; nt < DV / 16; ++nt) dv[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    dk[0] = dk[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int qc = 0; qc < Lq; qc += AT_CH) {
+        __syncthreads();
+        stage_rows(dolds, dOn, qc, Lq, DV);
+        for (int idx = threadIdx.x; idx < AT_CH * 4; idx += 256) {
+            const int r = idx >> 2, c = idx & 3;
+            bf16x8 v = zero8();
+            if (qc + r < Lq && c * 8 < dqk) v = *(const bf16x8*)(Qn + (long)(qc + r) * dqk + c * 8);
+            *(bf16x8*)(qlds + r * 32 + c * 8) = v;
+        }
+        __syncthreads();
+        f32x4 p[2], ds[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {                              // tile t: rows = queries qc+16t.., cols = keys
+            const long qrow = qc + 16 * t + lr;
+            const bf16x8 qa = rowfrag(Qn, qrow, Lq, dqk, lg);
+            p[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            ds[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < DV / 32; ++s) {                    // dP tile: rows = queries, cols = keys
+                bf16x8 da = zero8();
+                if (qrow < Lq) da = *(const bf16x8*)(dOn + qrow * DV + 32 * s + 8 * lg);
+                ds[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[s], ds[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long q = qc + 16 * t + 4 * lg + r;           // query (row) of this accumulator element
+                const bool ok = q < Lq && k0 + lr < Lk;
+                const float pr = ok ? __expf(p[t][r] - LSE[n * Lq + q]) : 0.f;
+                const float dlt = ok ? delta[n * Lq + q] : 0.f;
+                p[t][r] = pr;                                      // P[q][key lr]
+                ds[t][r] = pr * (ds[t][r] - dlt);                  // dS[q][key lr]
+            }
+        }
+        const bf16x8 pa = pack2(p[0], p[1]);                       // A: [key lr][k-slot (g,j) = query pi(g,j)]
+        const bf16x8 dsa = pack2(ds[0], ds[1]);
+#pragma unroll
+        for (int nt = 0; nt < DV / 16; ++nt)
+            dv[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, trfrag(dolds, DV, nt * 16, lr, lg), dv[nt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+            dk[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsa, trfrag(qlds, 32, nt * 16, lr, lg), dk[nt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const long k = k0 + 4 * lg + r;
+        if (k >= Lk) continue;
+#pragma unroll
+        for (int nt = 0; nt < DV / 16; ++nt) dV[(n * Lk + k) * DV + nt * 16 + lr] = f2bf(dv[nt][r]);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+            if (nt * 16 + lr < dqk) dK[(n * Lk + k) * dqk + nt * 16 + lr] = f2bf(dk[nt][r]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+static bool attn_args_ok(int dqk, int dv) { return dqk >= 8 && dqk <= 32 && dqk % 8 == 0 && (dv == 32 || dv == 64 || dv == 128); }
+
+extern "C" int ieagan_nl_attention_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int N, int Lq, int Lk,
+                                       int dqk, int dv, void* stream) {
+    CHECK_ARG(attn_args_ok(dqk, dv), "nl_attention: d_qk must be 8..32 (multiple of 8) and d_v in {32,64,128} (got %d, %d)", dqk, dv);
+    hipStream_t st = (hipStream_t)stream;
+    const double flops = 2.0 * N * (double)Lq * Lk * (dqk + dv);
+    ProfScope prof("nl_attention_fwd", flops, 2.0 * N * ((double)Lq * (dqk + dv) + (double)Lk * (dqk + dv)), st);
+    dim3 grid((Lq + 63) / 64, N);
+#define L(D) hipLaunchKernelGGL((nl_attn_fwd_kernel<D>), grid, dim3(256), 0, st, (const bf16*)Q, (const bf16*)K, (const bf16*)V, (bf16*)O, LSE, Lq, Lk, dqk)
+    if (dv == 32) L(32); else if (dv == 64) L(64); else L(128);
+#undef L
+    CHECK_LAUNCH("nl_attention_fwd");
+    return 0;
+}
+
+extern "C" int ieagan_nl_attention_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
+                                       float* delta, void* dQ, void* dK, void* dV, int N, int Lq, int Lk, int dqk, int dv,
+                                       void* stream) {
+    CHECK_ARG(attn_args_ok(dqk, dv), "nl_attention: d_qk must be 8..32 (multiple of 8) and d_v in {32,64,128} (got %d, %d)", dqk, dv);
+    hipStream_t st = (hipStream_t)stream;
+    const double flops = 2.0 * N * (double)Lq * Lk * (3.0 * dqk + 2.0 * dv) + 2.0 * N * (double)Lq * Lk * (dqk + dv);
+    ProfScope prof("nl_attention_bwd", flops, 4.0 * N * ((double)Lq * (dqk + dv) + (double)Lk * (dqk + dv)), st);
+    dim3 gq((Lq + 63) / 64, N), gk((Lk + 63) / 64, N);
+#define L(D)                                                                                                                   \
+    hipLaunchKernelGGL((nl_attn_bwd_q_kernel<D>), gq, dim3(256), 0, st, (const bf16*)Q, (const bf16*)K, (const bf16*)V,       \
+                       (const bf16*)O, (const bf16*)dO, LSE, delta, (bf16*)dQ, Lq, Lk, dqk);                                   \
+    hipLaunchKernelGGL((nl_attn_bwd_k_kernel<D>), gk, dim3(256), 0, st, (const bf16*)Q, (const bf16*)K, (const bf16*)V,       \
+                       (const bf16*)dO, LSE, (const float*)delta, (bf16*)dK, (bf16*)dV, Lq, Lk, dqk)
+    if (dv == 32) { L(32); } else if (dv == 64) { L(64); } else { L(128); }
+#undef L
+    CHECK_LAUNCH("nl_attention_bwd");
+    return 0;
+}

@@ -299,97 +299,174 @@ static int launch_gather_pro(const ConvArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// conv3x3_halo: output tile 8 rows x 32 columns per block.  The (8+2) x (32+2) input halo is staged ONCE
-// in LDS with the prologue (BN apply, ReLU, upsample source mapping) already applied, so the nine taps
-// read transformed bf16 pixels with ds_read_b128 instead of re-gathering and re-transforming from L1.
+// conv3x3_halo: output tile 8 rows x 32 columns.  The (8+2) x (32+2) input halo is staged ONCE in LDS with
+// the prologue (BN apply, ReLU, upsample source mapping) already applied, so the nine taps read transformed
+// bf16 pixels with ds_read_b128 instead of re-gathering and re-transforming from L1.
 // LDS pixel stride = Cin*2 + 16 bytes: 16 consecutive pixels land on 16 distinct 16-byte bank slots.
-// Wave w owns tile rows 2w, 2w+1 (4 m-tiles of 16 pixels).  Weights: global/L1 (small, shared).
+// Wave w owns tile rows 2w, 2w+1 (4 m-tiles of 16 pixels).
+//
+// PF > 0 (small Cin, the HBM-bound layers): a block walks `tpb` consecutive tiles; while tile t is in the
+// MFMA loop the raw halo of tile t+1 is already in flight into PF x 16-byte registers per thread (the
+// weights sit in LDS, so nothing in the loop waits on the vector-memory counter), i.e. global-memory
+// latency is hidden inside the block instead of relying on occupancy alone.
+// PF == 0: one tile per block, halo staged directly, weights from global/L1 (large Cin, MFMA-bound).
 // ------------------------------------------------------------------------------------------------
 #define HT_H 8
 #define HT_W 32
 
-template <bool AFF, bool RELU, int RS, int NT>
-__global__ __launch_bounds__(256) void conv3x3_halo_kernel(ConvArgs a, int tiles_w, int tiles_h, int nblk) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+template <bool AFF, bool RELU, int RS, int NT, int PF>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(ConvArgs a, int tiles_w, int tiles_h, int ntiles, int tpb, int nblk) {
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];
     __shared__ float red[4 * NT * 16 * 2];
+    constexpr int AW = HT_W + 2, AH = HT_H + 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 15, lg = lane >> 4;
     const int H = a.H, W = a.W, Cin = a.Cin;
     const int PS = Cin * 2 + 16;                           // bytes per halo pixel
-    // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2), so give each XCD a contiguous
-    // run of tiles -- neighbouring tiles then share their halo rows / weights through one L2.
+    const int WS = a.Kpad * 2 + 16;                        // bytes per weight row in LDS (PF > 0)
+    const int n_base = blockIdx.y * NT * 16;
+    const int chunks = Cin >> 3;
+    const int total = AH * AW * chunks;
+    char* smem = smem_all + (PF > 0 ? NT * 16 * WS : 0);   // halo (and, after the MFMA loop, epilogue) region
+    // XCD-aware order: blocks b and b+8 share an XCD (and its L2), so give each XCD a contiguous run of
+    // tiles -- neighbouring tiles then share their halo rows / weights through one L2.
     int bid = blockIdx.x;
     {
         const int q = nblk / 8, r = nblk % 8, xcd = bid % 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
     }
-    const int n = bid / (tiles_w * tiles_h);
-    const int trem = bid - n * tiles_w * tiles_h;
-    const int h0 = (trem / tiles_w) * HT_H, w0 = (trem % tiles_w) * HT_W;
-    const int n_base = blockIdx.y * NT * 16;
-    constexpr int AW = HT_W + 2, AH = HT_H + 2;
-
-    // ---- stage the halo
-    const int chunks = Cin >> 3;
-    for (int idx = threadIdx.x; idx < AH * AW * chunks; idx += 256) {
-        const int hp = idx / chunks, cc = idx - hp * chunks;
-        const int hh = h0 - 1 + hp / AW, ww = w0 - 1 + hp % AW;
-        const bf16x8 v = gather8<AFF, RELU, RS>(a.src, H, W, n, hh, ww, cc * 8, true);
-        *(bf16x8*)(smem + hp * PS + cc * 16) = v;
-    }
-    __syncthreads();
-
-    f32x4 acc[4][NT];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int ksteps = a.Kpad >> 5;
+    const int t0 = bid * tpb;
+    const int t1 = min(t0 + tpb, ntiles);
     const bool col_ok = (n_base + (NT - 1) * 16 + lr) < a.Cout;
-    const bf16* wrow = (const bf16*)a.w + (long)(col_ok ? n_base + lr : 0) * a.Kpad + lg * 8;
-    // byte offset of this lane's pixel in m-tile mt at tap (0,0): row 2*wave + (mt>>1), col (mt&1)*16 + lr
-    int pbase[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) pbase[mt] = ((2 * wave + (mt >> 1)) * AW + (mt & 1) * 16 + lr) * PS;
-    for (int ks = 0; ks < ksteps; ++ks) {
-        const int k = ks * 32 + lg * 8;
-        int tap = k / Cin;
-        const int c = k - tap * Cin;
-        const bool kval = tap < 9;
-        if (!kval) tap = 0;
-        const int toff = ((tap / 3) * AW + (tap - (tap / 3) * 3)) * PS + c * 2;
-        bf16x8 bfrag[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            bfrag[nt] = *(const bf16x8*)(wrow + (long)nt * 16 * a.Kpad + ks * 32);
-            if (NT == 1 && !col_ok) bfrag[nt] = zero8();
-        }
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            bf16x8 af = *(const bf16x8*)(smem + pbase[mt] + toff);
-            if (!kval) af = zero8();
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfrag[nt], acc[mt][nt], 0, 0, 0);
+
+    if (PF > 0) {   // weights -> LDS once per block
+        const int wchunks = a.Kpad >> 3;
+        for (int idx = threadIdx.x; idx < NT * 16 * wchunks; idx += 256) {
+            const int row = idx / wchunks, kc = idx - row * wchunks;
+            bf16x8 v = zero8();
+            if (n_base + row < a.Cout) v = *(const bf16x8*)((const bf16*)a.w + (long)(n_base + row) * a.Kpad + kc * 8);
+            *(bf16x8*)(smem_all + row * WS + kc * 16) = v;
         }
     }
-    __syncthreads();                                       // halo no longer needed: reuse LDS for the epilogue
-    float* epi = (float*)smem + wave * EpiLds<NT>::FLOATS;
+    bf16x8 raw[PF > 0 ? PF : 1];
+    unsigned okmask = 0;
+    auto tile_coords = [&](int t, int& n, int& h0, int& w0) {
+        n = t / (tiles_w * tiles_h);
+        const int trem = t - n * tiles_w * tiles_h;
+        h0 = (trem / tiles_w) * HT_H;
+        w0 = (trem % tiles_w) * HT_W;
+    };
+    auto load_tile = [&](int t) {      // raw 16-byte loads of the halo of tile t (no transform yet)
+        int n, h0, w0;
+        tile_coords(t, n, h0, w0);
+        okmask = 0;
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            const int idx = threadIdx.x + j * 256;
+            const int hp = idx / chunks, cc = idx - hp * chunks;
+            const int hh = h0 - 1 + hp / AW, ww = w0 - 1 + hp % AW;
+            const bool ok = idx < total && hh >= 0 && hh < H && ww >= 0 && ww < W;
+            if (ok) {
+                const int sh_ = (RS == 1) ? (hh >> 1) : hh, sw_ = (RS == 1) ? (ww >> 1) : ww;
+                raw[j] = *(const bf16x8*)((const bf16*)a.src.x + (((long)n * a.src.Hs + sh_) * a.src.Ws + sw_) * a.src.Cx + cc * 8);
+                okmask |= 1u << j;
+            }
+        }
+    };
+    auto store_tile = [&](int t) {     // prologue transform + LDS write of the prefetched halo
+        int n, h0, w0;
+        tile_coords(t, n, h0, w0);
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            const int idx = threadIdx.x + j * 256;
+            if (idx >= total) continue;
+            const int hp = idx / chunks, cc = idx - hp * chunks;
+            bf16x8 o = zero8();
+            if (okmask & (1u << j)) {
+                if (AFF || RELU) {
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = bf2f(raw[j][i]);
+                    xform8<AFF, RELU>(v, a.src, n, cc * 8);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) o[i] = f2bf(v[i]);
+                } else {
+                    o = raw[j];
+                }
+            }
+            *(bf16x8*)(smem + hp * PS + cc * 16) = o;
+        }
+    };
+
     float s1[8], s2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
+    int pbase[4];   // byte offset of this lane's pixel in m-tile mt at tap (0,0): row 2*wave + (mt>>1), col (mt&1)*16 + lr
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {                 // tile row 2*wave + half: 32 pixels
-        const int hh = h0 + 2 * wave + half;
-        auto pix = [&](int row, long& m, int& nn, int& h, int& w) -> bool {
-            nn = n;
-            h = hh;
-            w = w0 + row;
-            m = ((long)n * H + h) * W + w;
-            return h < H && w < W;
-        };
-        const f32x4(&sub)[2][NT] = *reinterpret_cast<const f32x4(*)[2][NT]>(&acc[2 * half]);
-        conv_epilogue<NT>(a, sub, epi, n_base, pix, s1, s2);
+    for (int mt = 0; mt < 4; ++mt) pbase[mt] = ((2 * wave + (mt >> 1)) * AW + (mt & 1) * 16 + lr) * PS;
+    const int ksteps = a.Kpad >> 5;
+    const bf16* wrow = (const bf16*)a.w + (long)(col_ok ? n_base + lr : 0) * a.Kpad + lg * 8;
+
+    if (PF > 0 && t0 < t1) load_tile(t0);
+    for (int t = t0; t < t1; ++t) {
+        int n, h0, w0;
+        tile_coords(t, n, h0, w0);
+        if (PF > 0) {
+            store_tile(t);
+        } else {
+            for (int idx = threadIdx.x; idx < total; idx += 256) {
+                const int hp = idx / chunks, cc = idx - hp * chunks;
+                const int hh = h0 - 1 + hp / AW, ww = w0 - 1 + hp % AW;
+                const bf16x8 v = gather8<AFF, RELU, RS>(a.src, H, W, n, hh, ww, cc * 8, true);
+                *(bf16x8*)(smem + hp * PS + cc * 16) = v;
+            }
+        }
+        __syncthreads();
+        if (PF > 0 && t + 1 < t1) load_tile(t + 1);       // in flight during the MFMA loop below
+
+        f32x4 acc[4][NT];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < ksteps; ++ks) {
+            const int k = ks * 32 + lg * 8;
+            int tap = k / Cin;
+            const int c = k - tap * Cin;
+            const bool kval = tap < 9;
+            if (!kval) tap = 0;
+            const int toff = ((tap / 3) * AW + (tap - (tap / 3) * 3)) * PS + c * 2;
+            bf16x8 bfrag[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if (PF > 0) bfrag[nt] = *(const bf16x8*)(smem_all + (nt * 16 + lr) * WS + k * 2);
+                else bfrag[nt] = *(const bf16x8*)(wrow + (long)nt * 16 * a.Kpad + ks * 32);
+                if (NT == 1 && !col_ok) bfrag[nt] = zero8();
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                bf16x8 af = *(const bf16x8*)(smem + pbase[mt] + toff);
+                if (!kval) af = zero8();
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfrag[nt], acc[mt][nt], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                   // halo consumed: its LDS becomes the epilogue buffer
+        float* epi = (float*)smem + wave * EpiLds<NT>::FLOATS;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {             // tile row 2*wave + half: 32 pixels
+            const int hh = h0 + 2 * wave + half;
+            auto pix = [&](int row, long& m, int& nn, int& h, int& w) -> bool {
+                nn = n;
+                h = hh;
+                w = w0 + row;
+                m = ((long)n * H + h) * W + w;
+                return h < H && w < W;
+            };
+            const f32x4(&sub)[2][NT] = *reinterpret_cast<const f32x4(*)[2][NT]>(&acc[2 * half]);
+            conv_epilogue<NT>(a, sub, epi, n_base, pix, s1, s2);
+        }
     }
     if (a.stats != nullptr) stats_flush<NT>(a, s1, s2, n_base, red, bid);
 }
@@ -397,19 +474,28 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(ConvArgs a, int tiles
 template <bool AFF, bool RELU, int RS>
 static int launch_halo_nt(const ConvArgs& a, hipStream_t st) {
     const int tiles_w = (a.W + HT_W - 1) / HT_W, tiles_h = (a.H + HT_H - 1) / HT_H;
-    const int nblk = a.N * tiles_w * tiles_h;
+    const int ntiles = a.N * tiles_w * tiles_h;
     const size_t halo = (size_t)(HT_H + 2) * (HT_W + 2) * (a.Cin * 2 + 16);
-#define HALO_LAUNCH(NTV)                                                                                     \
+    int tpb = ntiles / 2048;
+    if (tpb < 1) tpb = 1;
+    if (tpb > 8) tpb = 8;
+#define HALO_LAUNCH(NTV, PFV)                                                                                \
     {                                                                                                        \
         size_t lds = halo;                                                                                   \
         const size_t epi = (size_t)4 * EpiLds<NTV>::FLOATS * 4;                                              \
         if (epi > lds) lds = epi;                                                                            \
-        hipLaunchKernelGGL((conv3x3_halo_kernel<AFF, RELU, RS, NTV>), dim3(nblk, (a.Cout + 16 * NTV - 1) / (16 * NTV)), \
-                           dim3(256), lds, st, a, tiles_w, tiles_h, nblk);                                   \
+        const int tp = (PFV) > 0 ? tpb : 1;                                                                  \
+        if ((PFV) > 0) lds += (size_t)NTV * 16 * (a.Kpad * 2 + 16);                                          \
+        const int nblk = (ntiles + tp - 1) / tp;                                                             \
+        hipLaunchKernelGGL((conv3x3_halo_kernel<AFF, RELU, RS, NTV, PFV>), dim3(nblk, (a.Cout + 16 * NTV - 1) / (16 * NTV)), \
+                           dim3(256), lds, st, a, tiles_w, tiles_h, ntiles, tp, nblk);                       \
     }
-    if (a.Cout % 64 == 0) HALO_LAUNCH(4)
-    else if (a.Cout % 32 == 0) HALO_LAUNCH(2)
-    else HALO_LAUNCH(1)
+    // prefetching variants: Cin = Cout = 16 / 32 (PF = ceil(340 * Cin/8 / 256) = 3 / 6)
+    if (a.Cin == 16 && a.Cout == 16) HALO_LAUNCH(1, 3)
+    else if (a.Cin == 32 && a.Cout == 32) HALO_LAUNCH(2, 6)
+    else if (a.Cout % 64 == 0) HALO_LAUNCH(4, 0)
+    else if (a.Cout % 32 == 0) HALO_LAUNCH(2, 0)
+    else HALO_LAUNCH(1, 0)
 #undef HALO_LAUNCH
     return 0;
 }

@@ -84,7 +84,7 @@ class _DivSigma(torch.autograd.Function):
         for k in ops.SNRecord.__slots__:
             setattr(plain, k, getattr(rec, k))
         plain.kind = ops.KIND_PLAIN
-        return ops.sn_backward(g.contiguous().view(rec.out, rec.inn), weight, plain), None
+        return ops.sn_backward(g.contiguous().view(rec.out, rec.inn), weight, plain)[0], None
 
 
 class SNConv2d(nn.Conv2d, SN):
@@ -162,8 +162,8 @@ class Attention(nn.Module):
         return [(f"{prefix}.{n}", getattr(self, n)) for n in ("theta", "phi", "g", "o")]
 
     def fused(self, xa, recs, prefix):
-        """xa: bf16 [N,H,W,C].  1x1 convs in HIP; the (HW x HW/4) affinity uses the library bmm/softmax
-        (interim: a streaming-softmax HIP kernel replaces it)."""
+        """xa: bf16 [N,H,W,C].  theta/phi/g/o 1x1 convs and the streaming-softmax affinity are HIP kernels;
+        the 2x2 max-pool of phi / g and the final gamma*o + x are small library element-wise ops."""
         N, Hh, Ww, C = xa.shape
         theta, _ = self.theta.fused(xa, recs[prefix + ".theta"])
         phi, _ = self.phi.fused(xa, recs[prefix + ".phi"])
@@ -176,8 +176,7 @@ class Attention(nn.Module):
         q = theta.view(N, Hh * Ww, C // 8)
         k = phi.view(N, Hh * Ww // 4, C // 8)
         v = g.view(N, Hh * Ww // 4, C // 2)
-        beta = F.softmax(torch.bmm(q, k.transpose(1, 2)).float(), -1).to(q.dtype)
-        o_pre = torch.bmm(beta, v).view(N, Hh, Ww, C // 2)
+        o_pre = ops.NLAttentionFn.apply(q, k, v).view(N, Hh, Ww, C // 2)
         o, _ = self.o.fused(o_pre, recs[prefix + ".o"])
         return (self.gamma * o.float() + xa.float()).to(xa.dtype)
 

@@ -652,6 +652,37 @@ def channel_stats(x: torch.Tensor) -> torch.Tensor:
 
 
 # =====================================================================================================
+# non-local attention core
+# =====================================================================================================
+class NLAttentionFn(torch.autograd.Function):
+    """o = softmax(theta^T phi) g with a streaming softmax on MFMA (no [N, Lq, Lk] tensor; layers.py:291-299)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v):
+        N, Lq, dqk = q.shape
+        Lk, dv = k.shape[1], v.shape[2]
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        o = torch.empty(N, Lq, dv, dtype=BF16, device=q.device)
+        lse = torch.empty(N, Lq, dtype=torch.float32, device=q.device)
+        H.call("ieagan_nl_attention_fwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), N, Lq, Lk, dqk,
+               dv, H.stream())
+        ctx.save_for_backward(q, k, v, o, lse)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        N, Lq, dqk = q.shape
+        Lk, dv = k.shape[1], v.shape[2]
+        do = do.contiguous()
+        delta = torch.empty(N, Lq, dtype=torch.float32, device=q.device)
+        dq, dk, dvv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        H.call("ieagan_nl_attention_bwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
+               delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dvv.data_ptr(), N, Lq, Lk, dqk, dv, H.stream())
+        return dq, dk, dvv
+
+
+# =====================================================================================================
 # augmentation
 # =====================================================================================================
 class DiffAugFn(torch.autograd.Function):

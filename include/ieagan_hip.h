@@ -122,6 +122,14 @@ int ieagan_sn_backward_stack(const long* table, const int* layers, const long* r
                              const float* gst, const float* params, const float* ctx, float* grad_base, int accumulate,
                              void* stream);
 
+/* ---- non-local self-attention core (attention.hip): softmax(theta^T phi) applied to g, layers.py:291-299,
+ * streaming softmax (no [N, Lq, Lk] tensor).  Q [N,Lq,dqk], K [N,Lk,dqk], V [N,Lk,dv], O [N,Lq,dv] bf16;
+ * LSE, delta [N,Lq] fp32.  No 1/sqrt(d) scaling (as the reference). ------------------------------------ */
+int ieagan_nl_attention_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, int N, int Lq, int Lk,
+                            int dqk, int dv, void* stream);
+int ieagan_nl_attention_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
+                            float* delta, void* dQ, void* dK, void* dV, int N, int Lq, int Lk, int dqk, int dv, void* stream);
+
 /* ---- augmentation + optimiser (aug_optim.hip) -------------------------------------------------- */
 int ieagan_diffaug_fwd(const float* x, const float* bright, const float* contrast, const long* tx, const long* ty,
                        const long* ox, const long* oy, float* sums, float* out, int N, int H, int W, void* stream);

@@ -377,3 +377,22 @@ def test_adam_and_ema(dev, golden_dir):
     dec = torch.tensor([0.9], device=dev)
     _hip.call("ieagan_ema_update", t.data_ptr(), s.data_ptr(), 1000, dec.data_ptr(), _hip.stream())
     close(t, exp, 1e-6, "ema")
+
+
+@pytest.mark.parametrize("N,Lq,Lk,dqk,dv", [(2, 256, 64, 8, 32), (3, 192, 96, 32, 128), (2, 150, 70, 16, 64)])
+def test_nl_attention_forward_backward(dev, N, Lq, Lk, dqk, dv):
+    """Streaming-softmax attention core vs softmax(QK^T)V in fp32 (incl. ragged Lq / Lk tails)."""
+    import ops
+    torch.manual_seed(11)
+    q = r16(torch.randn(N, Lq, dqk, device=dev) * 0.7).requires_grad_(True)
+    k = r16(torch.randn(N, Lk, dqk, device=dev) * 0.7).requires_grad_(True)
+    v = r16(torch.randn(N, Lk, dv, device=dev)).requires_grad_(True)
+    go = r16(torch.randn(N, Lq, dv, device=dev))
+    ref = torch.softmax(q @ k.transpose(1, 2), -1) @ v
+    gref = torch.autograd.grad((ref * go).sum(), [q, k, v])
+    q2, k2, v2 = (t.detach().to(BF).requires_grad_(True) for t in (q, k, v))
+    out = ops.NLAttentionFn.apply(q2, k2, v2)
+    close(out, ref, 1.5e-2, "attention out")
+    g = torch.autograd.grad((out.float() * go).sum(), [q2, k2, v2])
+    for nme, a, b in zip(("dq", "dk", "dv"), g, gref):
+        close(a, b, 3e-2, f"attention {nme}")
