@@ -279,9 +279,11 @@ template <int TAPS, bool AFF, bool RELU, int RS>
 static int launch_gather_nt(const ConvArgs& a, hipStream_t st) {
     const long M = (long)a.N * a.H * a.W;
     const unsigned gx = (unsigned)((M + 127) / 128);
-    if (a.Cout % 64 == 0) {
+    // tiny feature maps (4x12 ... 16x48): split the output channels over more blocks to cover the chip
+    const bool small4 = (long)gx * (a.Cout / 64) < 512, small2 = (long)gx * (a.Cout / 32) < 512;
+    if (a.Cout % 64 == 0 && !small4) {
         hipLaunchKernelGGL((conv_gather_kernel<TAPS, AFF, RELU, RS, 4>), dim3(gx, a.Cout / 64), dim3(256), 0, st, a);
-    } else if (a.Cout % 32 == 0) {
+    } else if (a.Cout % 32 == 0 && !(small4 && small2 && a.Cout % 64 == 0)) {
         hipLaunchKernelGGL((conv_gather_kernel<TAPS, AFF, RELU, RS, 2>), dim3(gx, a.Cout / 32), dim3(256), 0, st, a);
     } else {
         hipLaunchKernelGGL((conv_gather_kernel<TAPS, AFF, RELU, RS, 1>), dim3(gx, (a.Cout + 15) / 16), dim3(256), 0, st, a);
@@ -314,14 +316,15 @@ static int launch_gather_pro(const ConvArgs& a, hipStream_t st) {
 #define HT_H 8
 #define HT_W 32
 
-template <bool AFF, bool RELU, int RS, int NT, int PF>
+template <bool AFF, bool RELU, int RS, int NT, int PF, int CIN>
 __global__ __launch_bounds__(256) void conv3x3_halo_kernel(ConvArgs a, int tiles_w, int tiles_h, int ntiles, int tpb, int nblk) {
     extern __shared__ __attribute__((aligned(16))) char smem_all[];
     __shared__ float red[4 * NT * 16 * 2];
     constexpr int AW = HT_W + 2, AH = HT_H + 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 15, lg = lane >> 4;
-    const int H = a.H, W = a.W, Cin = a.Cin;
+    const int H = a.H, W = a.W;
+    const int Cin = (CIN > 0) ? CIN : a.Cin;              // compile-time for the prefetching variants: no runtime divisions
     const int PS = Cin * 2 + 16;                           // bytes per halo pixel
     const int WS = a.Kpad * 2 + 16;                        // bytes per weight row in LDS (PF > 0)
     const int n_base = blockIdx.y * NT * 16;
@@ -479,7 +482,7 @@ static int launch_halo_nt(const ConvArgs& a, hipStream_t st) {
     int tpb = ntiles / 2048;
     if (tpb < 1) tpb = 1;
     if (tpb > 8) tpb = 8;
-#define HALO_LAUNCH(NTV, PFV)                                                                                \
+#define HALO_LAUNCH(NTV, PFV, CINV)                                                                              \
     {                                                                                                        \
         size_t lds = halo;                                                                                   \
         const size_t epi = (size_t)4 * EpiLds<NTV>::FLOATS * 4;                                              \
@@ -487,15 +490,17 @@ static int launch_halo_nt(const ConvArgs& a, hipStream_t st) {
         const int tp = (PFV) > 0 ? tpb : 1;                                                                  \
         if ((PFV) > 0) lds += (size_t)NTV * 16 * (a.Kpad * 2 + 16);                                          \
         const int nblk = (ntiles + tp - 1) / tp;                                                             \
-        hipLaunchKernelGGL((conv3x3_halo_kernel<AFF, RELU, RS, NTV, PFV>), dim3(nblk, (a.Cout + 16 * NTV - 1) / (16 * NTV)), \
+        hipLaunchKernelGGL((conv3x3_halo_kernel<AFF, RELU, RS, NTV, PFV, CINV>), dim3(nblk, (a.Cout + 16 * NTV - 1) / (16 * NTV)), \
                            dim3(256), lds, st, a, tiles_w, tiles_h, ntiles, tp, nblk);                       \
     }
     // prefetching variants: Cin = Cout = 16 / 32 (PF = ceil(340 * Cin/8 / 256) = 3 / 6)
-    if (a.Cin == 16 && a.Cout == 16) HALO_LAUNCH(1, 3)
-    else if (a.Cin == 32 && a.Cout == 32) HALO_LAUNCH(2, 6)
-    else if (a.Cout % 64 == 0) HALO_LAUNCH(4, 0)
-    else if (a.Cout % 32 == 0) HALO_LAUNCH(2, 0)
-    else HALO_LAUNCH(1, 0)
+    // small feature maps: fewer channels per block so that the grid still covers the 256 CUs
+    const bool small = ntiles * ((a.Cout + 63) / 64) < 512;
+    if (a.Cin == 16 && a.Cout == 16) HALO_LAUNCH(1, 3, 16)
+    else if (a.Cin == 32 && a.Cout == 32) HALO_LAUNCH(2, 6, 32)
+    else if (a.Cout % 64 == 0 && !small) HALO_LAUNCH(4, 0, 0)
+    else if (a.Cout % 32 == 0 && !(small && ntiles * (a.Cout / 32) < 512)) HALO_LAUNCH(2, 0, 0)
+    else HALO_LAUNCH(1, 0, 0)
 #undef HALO_LAUNCH
     return 0;
 }
@@ -600,7 +605,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     bool t_ok[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int ntg = blockIdx.y * 16 + wave * 4 + j;
+        const int ntg = blockIdx.y * 16 + j * 4 + wave;          // round-robin: 9 n-tiles (3x3, C=16) -> 3/2/2/2 per wave
         t_ok[j] = ntg < nt_total;
         const int q = t_ok[j] ? ntg : 0;
         const int tap = q / cin_tiles;
