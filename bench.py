@@ -189,20 +189,35 @@ def main():
     if timing:
         recs = sorted(_hip.prof_collect(), key=lambda r: -r["ms"])
         total = sum(r["ms"] for r in recs) or 1.0
-        top = recs[0]
-        per_launch_ms = top["ms"] / max(top["launches"], 1)
-        if top["flops"] > 0:
-            ach = top["flops"] / (top["ms"] * 1e-3) / 1e12
-            roof = {"kernel": top["name"], "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_BF16_TFLOPS}
-        else:
-            ach = top["bytes"] / (top["ms"] * 1e-3) / 1e9
-            roof = {"kernel": top["name"], "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": ach / PEAK_HBM_GBS}
-        roof.update(traffic=None, launches=top["launches"], avg_launch_ms=per_launch_ms,
-                    share_of_kernel_time=top["ms"] / total,
-                    hbm_equiv_GBs=top["bytes"] / (top["ms"] * 1e-3) / 1e9 if top["bytes"] else None)
-        res["roofline"] = roof
+        ridge = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)          # ~312 FLOP/B
+        pmc = {}
+        try:      # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, corrected)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["families"]
+        except Exception:
+            pass
+
+        def roofline_of(r):
+            ai = r["flops"] / r["bytes"] if r["bytes"] else float("inf")
+            if r["flops"] > 0 and ai >= ridge / 4:      # near / above the ridge: price against the MFMA peak
+                ach = r["flops"] / (r["ms"] * 1e-3) / 1e12
+                out = {"kernel": r["name"], "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                       "frac": ach / PEAK_BF16_TFLOPS}
+            else:
+                ach = r["bytes"] / (r["ms"] * 1e-3) / 1e9
+                out = {"kernel": r["name"], "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                       "frac": ach / PEAK_HBM_GBS}
+            fam = pmc.get(r["name"].split(" ")[0])
+            out.update(traffic=fam["hbm_bytes_per_launch"] if fam else None,
+                       algorithmic_bytes_per_launch=r["bytes"] / max(r["launches"], 1),
+                       algorithmic_flops_per_launch=r["flops"] / max(r["launches"], 1), launches=r["launches"],
+                       avg_launch_ms=r["ms"] / max(r["launches"], 1), share_of_kernel_time=r["ms"] / total,
+                       arithmetic_intensity=ai if ai != float("inf") else None)
+            return out
+
+        res["roofline"] = roofline_of(recs[0])
+        mf = [r for r in recs if r["flops"] > 0 and r["bytes"] and r["flops"] / r["bytes"] >= ridge / 4]
+        if mf:
+            res["roofline_conv_mfma"] = roofline_of(mf[0])
         res["kernels"] = [{"name": r["name"], "launches": r["launches"], "ms_per_step": r["ms"] / prof_steps,
                            "tflops": (r["flops"] / (r["ms"] * 1e-3) / 1e12) if r["flops"] else None,
                            "GBs": (r["bytes"] / (r["ms"] * 1e-3) / 1e9) if r["bytes"] else None} for r in recs[:(60 if args.shape_tags else 12)]]

@@ -498,6 +498,8 @@ static int launch_halo_nt(const ConvArgs& a, hipStream_t st) {
     const bool small = ntiles * ((a.Cout + 63) / 64) < 512;
     if (a.Cin == 16 && a.Cout == 16) HALO_LAUNCH(1, 3, 16)
     else if (a.Cin == 32 && a.Cout == 32) HALO_LAUNCH(2, 6, 32)
+    // (C = 64 with LDS-resident weights + prefetch was measured SLOWER -- 195-245 vs 270-320 TFLOP/s: one block of
+    //  4 waves per CU leaves the ds_read -> MFMA latency exposed; it needs a hand-pipelined K loop first.)
     else if (a.Cout % 64 == 0 && !small) HALO_LAUNCH(4, 0, 0)
     else if (a.Cout % 32 == 0 && !(small && ntiles * (a.Cout / 32) < 512)) HALO_LAUNCH(2, 0, 0)
     else HALO_LAUNCH(1, 0, 0)
