@@ -40,11 +40,18 @@ class MultiheadAttention(nn.Module):
 
     def forward(self, x, return_attention=False, recs=None, prefix=""):
         B, S, _ = x.shape
-        qkv = _lin(self.qkv_proj, x, recs, prefix + ".qkv_proj")
-        qkv = qkv.reshape(B, S, self.num_heads, 3 * self.head_dim).permute(0, 2, 1, 3)
-        q, k, v = qkv.chunk(3, dim=-1)
-        vals, att = scaled_dot_product(q, k, v)
-        vals = vals.permute(0, 2, 1, 3).reshape(B, S, self.embed_dim)
+        qkv = _lin(self.qkv_proj, x, recs, prefix + ".qkv_proj")          # [B, S, H * 3*hd], head-interleaved
+        if not qkv.is_cuda:
+            import _hip
+            _hip.require_gpu()
+            raise RuntimeError("RRM of the MI355X path takes HIP tensors (no CPU fallback)")
+        if S <= 64:
+            import ops                                                    # fused HIP core: S x S affinity in LDS
+            vals, att = ops.RRMAttentionFn.apply(qkv, self.num_heads)
+        else:                                                             # > 64 tokens (joint fake+real pass): library path
+            q, k, v = qkv.reshape(B, S, self.num_heads, 3 * self.head_dim).permute(0, 2, 1, 3).chunk(3, dim=-1)
+            vals, att = scaled_dot_product(q, k, v)
+            vals = vals.permute(0, 2, 1, 3).reshape(B, S, self.embed_dim)
         o = _lin(self.o_proj, vals, recs, prefix + ".o_proj")
         return (o, att) if return_attention else o
 

@@ -67,6 +67,11 @@ _SIGS = {
     "ieagan_sn_backward_stack": [vp, vp, vp, vp, i, vp, vp, vp, vp, i, vp],
     "ieagan_nl_attention_fwd": [vp, vp, vp, vp, vp, i, i, i, i, i, vp],
     "ieagan_nl_attention_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, vp],
+    "ieagan_rrm_attention_fwd": [vp, vp, vp, i, i, i, i, vp],
+    "ieagan_rrm_attention_bwd": [vp, vp, vp, vp, i, i, i, i, vp],
+    "ieagan_loss_block": [vp, vp, vp, vp, vp, C.POINTER(C.c_float), f, vp, vp, vp, vp, vp, i, i, vp],
+    "ieagan_relu_sum_pool": [vp, vp, i, i, i, vp],
+    "ieagan_relu_sum_pool_bwd": [vp, vp, vp, i, i, i, vp],
     "ieagan_diffaug_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, vp],
     "ieagan_diffaug_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, vp],
     "ieagan_cr_diffaug": [vp, vp, vp, vp, vp, i, i, i, vp],

@@ -1,0 +1,448 @@
+// Small single-workgroup kernels of the train step (fp32; no MFMA -- 40 tokens are too few):
+//   rrm_attention   per (batch, head): softmax(q k^T / sqrt(hd)) v with the S x S affinity held in LDS
+//                   (RRM.py:10-16, 46-58).  Consumes the packed qkv projection [B,S,H,3*hd] directly and
+//                   writes [B,S,H*hd] for o_proj; backward returns d(qkv).
+//   loss_block      every loss of one phase on the [n] logits and [n, d] unit-sphere embeddings in ONE launch,
+//                   value AND gradient: hinge (dis / gen), 2C contrastive, uniformity, IEA (loss.py:8-44, 79-132).
+//                   The three embedding losses share one n x n Gram matrix, kept in LDS.
+//   relu_sum_pool   D head: sum_{h,w} relu(x) of a bf16 NHWC map -> [N, C] fp32, and its backward (model.py:912)
+#include "common.h"
+
+#define SMAX 64          // max tokens / samples handled by these kernels
+
+__device__ __forceinline__ float block_reduce_sum(float v, float* red) {   // blockDim.x <= 1024
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int i = 0; i < (int)((blockDim.x + 63) >> 6); ++i) s += red[i];
+    __syncthreads();
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RRM attention core.  grid (H, B), 256 threads.  LDS: q,k,v [S][hd] + att [S][S].
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rrm_attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, float* __restrict__ att_out,
+                                                           int S, int Hh, int hd) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int LD = hd + 1;                          // padded LDS row: consecutive tokens hit different banks
+    float* q = sm;
+    float* k = q + S * LD;
+    float* v = k + S * LD;
+    float* att = v + S * LD;                       // [S][S]
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int E3 = Hh * 3 * hd;
+    const float* base = qkv + (long)b * S * E3 + h * 3 * hd;
+    for (int idx = threadIdx.x; idx < S * hd; idx += 256) {
+        const int s = idx / hd, d = idx - s * hd;
+        q[s * LD + d] = base[(long)s * E3 + d];
+        k[s * LD + d] = base[(long)s * E3 + hd + d];
+        v[s * LD + d] = base[(long)s * E3 + 2 * hd + d];
+    }
+    __syncthreads();
+    const float scale = rsqrtf((float)hd);
+    for (int idx = threadIdx.x; idx < S * S; idx += 256) {
+        const int i = idx / S, j = idx - i * S;
+        float a = 0.f;
+        for (int d = 0; d < hd; ++d) a += q[i * LD + d] * k[j * LD + d];
+        att[idx] = a * scale;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < S; i += 256) {   // row softmax (S <= 64 rows)
+        float m = -1e30f;
+        for (int j = 0; j < S; ++j) m = fmaxf(m, att[i * S + j]);
+        float l = 0.f;
+        for (int j = 0; j < S; ++j) {
+            const float e = __expf(att[i * S + j] - m);
+            att[i * S + j] = e;
+            l += e;
+        }
+        const float il = 1.f / l;
+        for (int j = 0; j < S; ++j) att[i * S + j] *= il;
+    }
+    __syncthreads();
+    float* ao = att_out + ((long)b * Hh + h) * S * S;
+    for (int idx = threadIdx.x; idx < S * S; idx += 256) ao[idx] = att[idx];
+    const int E = Hh * hd;
+    for (int idx = threadIdx.x; idx < S * hd; idx += 256) {
+        const int i = idx / hd, d = idx - i * hd;
+        float a = 0.f;
+        for (int j = 0; j < S; ++j) a += att[i * S + j] * v[j * LD + d];
+        out[((long)b * S + i) * E + h * hd + d] = a;
+    }
+}
+
+__global__ __launch_bounds__(256) void rrm_attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ att_in,
+                                                           const float* __restrict__ dout, float* __restrict__ dqkv, int S, int Hh, int hd) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int LD = hd + 1;
+    float* q = sm;
+    float* k = q + S * LD;
+    float* v = k + S * LD;
+    float* go = v + S * LD;                        // dout of this head [S][hd]
+    float* att = go + S * LD;                      // [S][S]
+    float* ds = att + S * S;                       // d score [S][S]
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int E3 = Hh * 3 * hd, E = Hh * hd;
+    const float* base = qkv + (long)b * S * E3 + h * 3 * hd;
+    for (int idx = threadIdx.x; idx < S * hd; idx += 256) {
+        const int s = idx / hd, d = idx - s * hd;
+        q[s * LD + d] = base[(long)s * E3 + d];
+        k[s * LD + d] = base[(long)s * E3 + hd + d];
+        v[s * LD + d] = base[(long)s * E3 + 2 * hd + d];
+        go[s * LD + d] = dout[((long)b * S + s) * E + h * hd + d];
+    }
+    const float* ai = att_in + ((long)b * Hh + h) * S * S;
+    for (int idx = threadIdx.x; idx < S * S; idx += 256) att[idx] = ai[idx];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < S * S; idx += 256) {    // d att_ij = dout_i . v_j
+        const int i = idx / S, j = idx - i * S;
+        float a = 0.f;
+        for (int d = 0; d < hd; ++d) a += go[i * LD + d] * v[j * LD + d];
+        ds[idx] = a;
+    }
+    __syncthreads();
+    const float scale = rsqrtf((float)hd);
+    for (int i = threadIdx.x; i < S; i += 256) {               // softmax backward per row, folded with 1/sqrt(hd)
+        float dot = 0.f;
+        for (int j = 0; j < S; ++j) dot += att[i * S + j] * ds[i * S + j];
+        for (int j = 0; j < S; ++j) ds[i * S + j] = att[i * S + j] * (ds[i * S + j] - dot) * scale;
+    }
+    __syncthreads();
+    float* ob = dqkv + (long)b * S * E3 + h * 3 * hd;
+    for (int idx = threadIdx.x; idx < S * hd; idx += 256) {
+        const int i = idx / hd, d = idx - i * hd;
+        float dq = 0.f, dk = 0.f, dv = 0.f;
+        for (int j = 0; j < S; ++j) {
+            dq += ds[i * S + j] * k[j * LD + d];
+            dk += ds[j * S + i] * q[j * LD + d];
+            dv += att[j * S + i] * go[j * LD + d];
+        }
+        ob[(long)i * E3 + d] = dq;
+        ob[(long)i * E3 + hd + d] = dk;
+        ob[(long)i * E3 + 2 * hd + d] = dv;
+    }
+}
+
+extern "C" int ieagan_rrm_attention_fwd(const float* qkv, float* out, float* att, int B, int S, int H, int hd, void* stream) {
+    CHECK_ARG(S >= 1 && S <= SMAX && hd >= 1, "rrm_attention: S must be <= %d", SMAX);
+    const size_t lds = (size_t)(3 * S * (hd + 1) + S * S) * 4;
+    CHECK_ARG(lds <= 150 * 1024, "rrm_attention: head does not fit LDS");
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof("rrm_attention_fwd", 4.0 * B * H * S * S * hd, 0.0, st);
+    hipLaunchKernelGGL(rrm_attn_fwd_kernel, dim3(H, B), dim3(256), lds, st, qkv, out, att, S, H, hd);
+    CHECK_LAUNCH("rrm_attention_fwd");
+    return 0;
+}
+
+extern "C" int ieagan_rrm_attention_bwd(const float* qkv, const float* att, const float* dout, float* dqkv, int B, int S, int H, int hd,
+                                        void* stream) {
+    CHECK_ARG(S >= 1 && S <= SMAX && hd >= 1, "rrm_attention: S must be <= %d", SMAX);
+    const size_t lds = (size_t)(4 * S * (hd + 1) + 2 * S * S) * 4;
+    CHECK_ARG(lds <= 150 * 1024, "rrm_attention: head does not fit LDS");
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof("rrm_attention_bwd", 8.0 * B * H * S * S * hd, 0.0, st);
+    hipLaunchKernelGGL(rrm_attn_bwd_kernel, dim3(H, B), dim3(256), lds, st, qkv, att, dout, dqkv, S, H, hd);
+    CHECK_LAUNCH("rrm_attention_bwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// loss_block: one workgroup of 1024 threads.
+//   inputs (any may be null): dfake[n], dreal[n] logits; e[n,d] embeddings, p[n,d] proxies, er[n,d] real
+//   embeddings (IEA target, no gradient).  w[6] = weights of {hinge_real, hinge_fake, hinge_gen, contra,
+//   unif, iea} in the total (0 = term off; a term is evaluated iff its weight != 0 and its inputs exist).
+//   outputs: vals[8] = {total, hinge_real, hinge_fake, hinge_gen, contra, unif, iea, 0} (unweighted terms),
+//            g_dfake[n], g_dreal[n], g_e[n,d], g_p[n,d] = d total / d input.
+// ------------------------------------------------------------------------------------------------
+struct LossArgs {
+    const float* dfake;
+    const float* dreal;
+    const float* e;
+    const float* p;
+    const float* er;
+    float w[6];
+    float temperature;
+    float* vals;
+    float* g_dfake;
+    float* g_dreal;
+    float* g_e;
+    float* g_p;
+    int n, d;
+};
+
+// G[i][j] = sum_k A[i][k] B[j][k]; staged in k-chunks of 64 through LDS (A and B may alias)
+__device__ void gram(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ G, float* la, float* lb, int n, int d) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};                        // up to 4 (i,j) pairs per thread (n*n <= 4096)
+    for (int k0 = 0; k0 < d; k0 += 64) {
+        __syncthreads();
+        for (int idx = tid; idx < n * 64; idx += nt) {
+            const int i = idx >> 6, kk = idx & 63;
+            la[i * 65 + kk] = (k0 + kk < d) ? A[(long)i * d + k0 + kk] : 0.f;
+            lb[i * 65 + kk] = (k0 + kk < d) ? B[(long)i * d + k0 + kk] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int pr = tid + s * nt;
+            if (pr < n * n) {
+                const int i = pr / n, j = pr - i * n;
+                float a = 0.f;
+                for (int kk = 0; kk < 64; ++kk) a += la[i * 65 + kk] * lb[j * 65 + kk];
+                acc[s] += a;
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int pr = tid + s * nt;
+        if (pr < n * n) G[pr] = acc[s];
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void loss_block_kernel(LossArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ float red[16];
+    __shared__ float sc[8];
+    const int n = a.n, d = a.d, tid = threadIdx.x;
+    float* G = sm;                     // e e^T
+    float* R = G + n * n;              // er er^T (IEA target logits)
+    float* DG = R + n * n;             // d total / d G_ij  (G_ij and G_ji treated as separate variables)
+    float* la = DG + n * n;            // staging [n][65] x 2
+    float* lb = la + n * 65;
+    float* ep = lb + n * 65;           // e_i . p_i
+    float* pp = ep + n;                // p_i . p_i
+    float* dep = pp + n;               // d total / d (e.p)_i
+    float* dpp = dep + n;              // d total / d (p.p)_i
+    float* rowa = dpp + n;             // scratch [n]
+    float* rowb = rowa + n;
+    const float w_hr = a.w[0], w_hf = a.w[1], w_hg = a.w[2];
+    float w_c = a.w[3], w_u = a.w[4], w_i = a.w[5];
+    if (a.e == nullptr) w_c = w_u = w_i = 0.f;
+    if (a.p == nullptr) w_c = 0.f;
+    if (a.er == nullptr) w_i = 0.f;
+    if (tid < 8) sc[tid] = 0.f;
+    __syncthreads();
+
+    // ---- hinge terms on the logits (loss.py:30-38)
+    if (a.dfake != nullptr || a.dreal != nullptr) {
+        float hr = 0.f, hf = 0.f, hg = 0.f;
+        for (int i = tid; i < n; i += blockDim.x) {
+            float gf = 0.f;
+            if (a.dreal != nullptr) {
+                const float x = 1.f - a.dreal[i];
+                hr += fmaxf(x, 0.f);
+                if (a.g_dreal) a.g_dreal[i] = (x > 0.f) ? -w_hr / n : 0.f;
+            }
+            if (a.dfake != nullptr) {
+                const float x = 1.f + a.dfake[i];
+                hf += fmaxf(x, 0.f);
+                hg += -a.dfake[i];
+                gf = ((x > 0.f) ? w_hf / n : 0.f) - w_hg / n;
+                if (a.g_dfake) a.g_dfake[i] = gf;
+            }
+        }
+        hr = block_reduce_sum(hr, red);
+        hf = block_reduce_sum(hf, red);
+        hg = block_reduce_sum(hg, red);
+        if (tid == 0) {
+            sc[1] = hr / n;
+            sc[2] = hf / n;
+            sc[3] = hg / n;
+        }
+    }
+    const bool emb = (w_c != 0.f || w_u != 0.f || w_i != 0.f);
+    if (emb) {
+        gram(a.e, a.e, G, la, lb, n, d);
+        if (w_i != 0.f) gram(a.er, a.er, R, la, lb, n, d);
+        for (int idx = tid; idx < n * n; idx += blockDim.x) DG[idx] = 0.f;
+        if (w_c != 0.f) {      // e_i . p_i and p_i . p_i
+            for (int i = tid >> 4; i < n; i += blockDim.x >> 4) {       // 16 lanes per row
+                float s1 = 0.f, s2 = 0.f;
+                for (int k = tid & 15; k < d; k += 16) {
+                    const float pv = a.p[(long)i * d + k];
+                    s1 += a.e[(long)i * d + k] * pv;
+                    s2 += pv * pv;
+                }
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) {
+                    s1 += __shfl_xor(s1, o, 64);
+                    s2 += __shfl_xor(s2, o, 64);
+                }
+                if ((tid & 15) == 0) {
+                    ep[i] = s1;
+                    pp[i] = s2;
+                }
+            }
+        }
+        for (int i = tid; i < n; i += blockDim.x) dep[i] = dpp[i] = 0.f;
+        __syncthreads();
+
+        // ---- 2C contrastive (loss.py:103-132, pos_collected_numerator = False, margin 0)
+        if (w_c != 0.f) {
+            const float t = a.temperature;
+            float part = 0.f;
+            for (int i = tid; i < n; i += blockDim.x) {
+                const float ri = 1.f / fmaxf(sqrtf(G[i * n + i]), 1e-8f), si = 1.f / fmaxf(sqrtf(pp[i]), 1e-8f);
+                const float ci = ep[i] * ri * si;
+                const float pos = __expf(ci / t);
+                float den = pos;
+                for (int j = 0; j < n; ++j)
+                    if (j != i) den += __expf(G[i * n + j] * ri / fmaxf(sqrtf(G[j * n + j]), 1e-8f) / t);
+                part += -__logf(t * pos / den);
+                // L_i = -log t - c_i/t + log den ;  dL_i/dc_i = (-1 + pos/den)/t ;  dL_i/dcos_ij = exp(cos_ij/t)/den/t
+                const float cw = w_c / n;
+                const float B = cw * (-1.f + pos / den) / t;
+                dep[i] = B * ri * si;
+                dpp[i] = B * ci * (-0.5f / fmaxf(pp[i], 1e-16f));
+                float dgii = B * ci * (-0.5f / fmaxf(G[i * n + i], 1e-16f));
+                for (int j = 0; j < n; ++j) {
+                    if (j == i) continue;
+                    const float rj = 1.f / fmaxf(sqrtf(G[j * n + j]), 1e-8f);
+                    const float cij = G[i * n + j] * ri * rj;
+                    const float A = cw * __expf(cij / t) / den / t;           // d total / d cos_ij (row i)
+                    atomicAdd(&DG[i * n + j], A * ri * rj);
+                    dgii += A * cij * (-0.5f / fmaxf(G[i * n + i], 1e-16f));
+                    atomicAdd(&DG[j * n + j], A * cij * (-0.5f / fmaxf(G[j * n + j], 1e-16f)));
+                }
+                atomicAdd(&DG[i * n + i], dgii);
+            }
+            part = block_reduce_sum(part, red);
+            if (tid == 0) sc[4] = part / n;
+        }
+        __syncthreads();
+
+        // ---- uniformity: log mean_{i<j} exp(-2 |e_i - e_j|^2)   (loss.py:8-9)
+        if (w_u != 0.f) {
+            float part = 0.f;
+            for (int idx = tid; idx < n * n; idx += blockDim.x) {
+                const int i = idx / n, j = idx - i * n;
+                if (i < j) part += __expf(-2.f * fmaxf(G[i * n + i] + G[j * n + j] - 2.f * G[idx], 0.f));
+            }
+            const float tot = block_reduce_sum(part, red);
+            const float npairs = 0.5f * n * (n - 1);
+            if (tid == 0) sc[5] = __logf(tot / npairs);
+            for (int idx = tid; idx < n * n; idx += blockDim.x) {
+                const int i = idx / n, j = idx - i * n;
+                if (i < j) {
+                    const float wgt = w_u * __expf(-2.f * fmaxf(G[i * n + i] + G[j * n + j] - 2.f * G[idx], 0.f)) / tot;  // d/d(-2 d2)
+                    atomicAdd(&DG[i * n + i], -2.f * wgt);
+                    atomicAdd(&DG[j * n + j], -2.f * wgt);
+                    atomicAdd(&DG[idx], 4.f * wgt);
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- IEA: KL_batchmean(softmax(er er^T) || softmax(e e^T))   (loss.py:14-27)
+        if (w_i != 0.f) {
+            float part = 0.f;
+            for (int i = tid; i < n; i += blockDim.x) {
+                float mf = -1e30f, mr = -1e30f;
+                for (int j = 0; j < n; ++j) {
+                    mf = fmaxf(mf, G[i * n + j]);
+                    mr = fmaxf(mr, R[i * n + j]);
+                }
+                float lf = 0.f, lr_ = 0.f;
+                for (int j = 0; j < n; ++j) {
+                    lf += __expf(G[i * n + j] - mf);
+                    lr_ += __expf(R[i * n + j] - mr);
+                }
+                const float lsef = mf + __logf(lf), lser = mr + __logf(lr_);
+                for (int j = 0; j < n; ++j) {
+                    const float logp = G[i * n + j] - lsef, logt = R[i * n + j] - lser;
+                    const float T = __expf(logt);
+                    part += T * (logt - logp);
+                    atomicAdd(&DG[i * n + j], w_i * (__expf(logp) - T) / n);
+                }
+            }
+            part = block_reduce_sum(part, red);
+            if (tid == 0) sc[6] = part / n;
+        }
+        __syncthreads();
+
+        // ---- d total / d e_i = sum_j (DG_ij + DG_ji) e_j + dep_i p_i ;  d/dp_i = dep_i e_i + 2 dpp_i p_i
+        // (the diagonal DG_ii already counts once per appearance of G_ii; d G_ii / d e_i = 2 e_i)
+        for (int idx = tid; idx < n * d; idx += blockDim.x) {
+            const int i = idx / d, k = idx - i * d;
+            float g = 0.f;
+            for (int j = 0; j < n; ++j) {
+                const float c = (j == i) ? 2.f * DG[i * n + i] : DG[i * n + j] + DG[j * n + i];
+                g += c * a.e[(long)j * d + k];
+            }
+            if (w_c != 0.f) {
+                g += dep[i] * a.p[idx];
+                if (a.g_p) a.g_p[idx] = dep[i] * a.e[idx] + 2.f * dpp[i] * a.p[idx];
+            }
+            if (a.g_e) a.g_e[idx] = g;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        sc[0] = w_hr * sc[1] + w_hf * sc[2] + w_hg * sc[3] + w_c * sc[4] + w_u * sc[5] + w_i * sc[6];
+        for (int i = 0; i < 8; ++i) a.vals[i] = sc[i];
+    }
+    (void)rowa; (void)rowb;
+}
+
+extern "C" int ieagan_loss_block(const float* dfake, const float* dreal, const float* e, const float* p, const float* er,
+                                 const float* weights6, float temperature, float* vals8, float* g_dfake, float* g_dreal, float* g_e,
+                                 float* g_p, int n, int d, void* stream) {
+    CHECK_ARG(n >= 2 && n <= SMAX, "loss_block: n must be in [2, %d]", SMAX);
+    LossArgs a;
+    a.dfake = dfake; a.dreal = dreal; a.e = e; a.p = p; a.er = er;
+    for (int i = 0; i < 6; ++i) a.w[i] = weights6[i];
+    a.temperature = temperature;
+    a.vals = vals8; a.g_dfake = g_dfake; a.g_dreal = g_dreal; a.g_e = g_e; a.g_p = g_p;
+    a.n = n; a.d = d;
+    const size_t lds = (size_t)(3 * n * n + 2 * n * 65 + 6 * n) * 4;
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof("loss_block", 0.0, 0.0, st);
+    hipLaunchKernelGGL(loss_block_kernel, dim3(1), dim3(1024), lds, st, a);
+    CHECK_LAUNCH("loss_block");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// D head: h[n][c] = sum_{hw} relu(x[n,hw,c]); backward dx = (x > 0) * dh[n][c].  x bf16 NHWC.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void relu_sum_pool_kernel(const bf16* __restrict__ x, float* __restrict__ out, int HW, int C) {
+    const int n = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int p = 0; p < HW; ++p) s += fmaxf(bf2f(x[((long)n * HW + p) * C + c]), 0.f);
+    out[(long)n * C + c] = s;
+}
+
+__global__ __launch_bounds__(256) void relu_sum_pool_bwd_kernel(const bf16* __restrict__ x, const float* __restrict__ dh, bf16* __restrict__ dx,
+                                                                long total, int HW, int C) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const long n = i / ((long)HW * C);
+        dx[i] = f2bf(bf2f(x[i]) > 0.f ? dh[n * C + c] : 0.f);
+    }
+}
+
+extern "C" int ieagan_relu_sum_pool(const void* x, float* out, int N, int HW, int C, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof("relu_sum_pool", 0.0, 2.0 * N * HW * (double)C, st);
+    hipLaunchKernelGGL(relu_sum_pool_kernel, dim3(cdiv(C, 256), N), dim3(256), 0, st, (const bf16*)x, out, HW, C);
+    CHECK_LAUNCH("relu_sum_pool");
+    return 0;
+}
+
+extern "C" int ieagan_relu_sum_pool_bwd(const void* x, const float* dh, void* dx, int N, int HW, int C, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const long total = (long)N * HW * C;
+    ProfScope prof("relu_sum_pool_bwd", 0.0, 4.0 * total, st);
+    long blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(relu_sum_pool_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16*)x, dh, (bf16*)dx, total, HW, C);
+    CHECK_LAUNCH("relu_sum_pool_bwd");
+    return 0;
+}

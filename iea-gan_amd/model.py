@@ -374,7 +374,7 @@ class Discriminator(nn.Module):
             for bi, blk in enumerate(stage):
                 p = f"blocks.{si}.{bi}"
                 h = blk.fused(h, recs, p)
-        h = torch.sum(F.relu(h.float()), [1, 2])                                   # global sum pool -> [N, C]
+        h = ops.ReluSumPoolFn.apply(h)                                             # global sum pool of relu -> [N, C] fp32
         if self.conditional_strategy == "Contra":
             out = torch.squeeze(self.linear0.fused(h, recs["linear0"]))
             proxy = self.embed.fused(y, recs["embed"])

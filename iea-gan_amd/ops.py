@@ -48,8 +48,18 @@ class _ZeroPool:
         self.pos[key] = o + n_al
         return self.buf[key][o:o + n]
 
+    def reset(self):
+        """Drop the current chunks.  MUST bracket a HIP-graph capture: a chunk filled before the capture would be
+        carved inside it without its fill being part of the graph (stale accumulators on replay), and a chunk
+        allocated inside the capture belongs to the graph's private memory pool."""
+        self.buf, self.pos = {}, {}
+
 
 _ZEROS = _ZeroPool()
+
+
+def reset_zero_pool():
+    _ZEROS.reset()
 
 
 def zeros(shape, device) -> torch.Tensor:
@@ -680,6 +690,96 @@ class NLAttentionFn(torch.autograd.Function):
         H.call("ieagan_nl_attention_bwd", q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
                delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dvv.data_ptr(), N, Lq, Lk, dqk, dv, H.stream())
         return dq, dk, dvv
+
+
+# =====================================================================================================
+# small fused kernels: RRM attention core, loss block, D-head pooling
+# =====================================================================================================
+class RRMAttentionFn(torch.autograd.Function):
+    """softmax(q k^T / sqrt(hd)) v per (batch, head) on the packed projection [B,S,H*3*hd] -> [B,S,H*hd];
+    the S x S affinity lives in LDS (RRM.py:10-16, 46-58)."""
+
+    @staticmethod
+    def forward(ctx, qkv, num_heads):
+        B, S, E3 = qkv.shape
+        hd = E3 // (3 * num_heads)
+        qkv = qkv.contiguous().float()
+        out = torch.empty(B, S, num_heads * hd, dtype=torch.float32, device=qkv.device)
+        att = torch.empty(B, num_heads, S, S, dtype=torch.float32, device=qkv.device)
+        H.call("ieagan_rrm_attention_fwd", qkv.data_ptr(), out.data_ptr(), att.data_ptr(), B, S, num_heads, hd, H.stream())
+        ctx.num_heads = num_heads
+        ctx.save_for_backward(qkv, att)
+        ctx.mark_non_differentiable(att)
+        return out, att
+
+    @staticmethod
+    def backward(ctx, dout, _datt):
+        qkv, att = ctx.saved_tensors
+        B, S, E3 = qkv.shape
+        hd = E3 // (3 * ctx.num_heads)
+        dqkv = torch.empty_like(qkv)
+        H.call("ieagan_rrm_attention_bwd", qkv.data_ptr(), att.data_ptr(), dout.contiguous().float().data_ptr(), dqkv.data_ptr(), B, S,
+               ctx.num_heads, hd, H.stream())
+        return dqkv, None
+
+
+class LossBlockFn(torch.autograd.Function):
+    """All losses of one phase, value and gradient, in one launch (loss.py:8-44, 79-132).
+    Returns (total, terms[8]); only ``total`` is differentiable."""
+
+    @staticmethod
+    def forward(ctx, dfake, dreal, e, p, er, weights, temperature):
+        import ctypes
+        ref = next(t for t in (dfake, dreal, e) if t is not None)
+        dev = ref.device
+        n = ref.shape[0]
+        d = e.shape[1] if e is not None else 0
+        c = lambda t: None if t is None else t.contiguous().float()
+        dfake, dreal, e, p, er = c(dfake), c(dreal), c(e), c(p), c(er)
+        vals = torch.empty(8, dtype=torch.float32, device=dev)
+        g_df = torch.empty_like(dfake) if dfake is not None else None
+        g_dr = torch.empty_like(dreal) if dreal is not None else None
+        g_e = torch.empty_like(e) if e is not None else None
+        g_p = torch.empty_like(p) if p is not None else None
+        w = (ctypes.c_float * 6)(*[float(x) for x in weights])
+        H.call("ieagan_loss_block", H.ptr(dfake), H.ptr(dreal), H.ptr(e), H.ptr(p), H.ptr(er), w, float(temperature),
+               vals.data_ptr(), H.ptr(g_df), H.ptr(g_dr), H.ptr(g_e), H.ptr(g_p), n, d, H.stream())
+        ctx.save_for_backward(g_df, g_dr, g_e, g_p)
+        terms = vals.clone()
+        ctx.mark_non_differentiable(terms)
+        return vals[0], terms
+
+    @staticmethod
+    def backward(ctx, gtotal, _gterms):
+        g_df, g_dr, g_e, g_p = ctx.saved_tensors
+        m = lambda t: None if t is None else t * gtotal
+        return m(g_df), m(g_dr), m(g_e), m(g_p), None, None, None
+
+
+def loss_block(dfake=None, dreal=None, e=None, p=None, er=None, w_hinge_real=0.0, w_hinge_fake=0.0, w_hinge_gen=0.0,
+               w_contra=0.0, w_unif=0.0, w_iea=0.0, temperature=1.0):
+    """(total, terms) with terms = [total, hinge_real, hinge_fake, hinge_gen, contrastive, uniformity, iea, 0]."""
+    return LossBlockFn.apply(dfake, dreal, e, p, er, (w_hinge_real, w_hinge_fake, w_hinge_gen, w_contra, w_unif, w_iea), temperature)
+
+
+class ReluSumPoolFn(torch.autograd.Function):
+    """D head: sum over (h, w) of relu(x), bf16 NHWC -> fp32 [N, C]  (model.py:912)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        N, Hh, Ww, C = x.shape
+        out = torch.empty(N, C, dtype=torch.float32, device=x.device)
+        H.call("ieagan_relu_sum_pool", x.data_ptr(), out.data_ptr(), N, Hh * Ww, C, H.stream())
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, dh):
+        (x,) = ctx.saved_tensors
+        N, Hh, Ww, C = x.shape
+        dx = torch.empty_like(x)
+        H.call("ieagan_relu_sum_pool_bwd", x.data_ptr(), dh.contiguous().float().data_ptr(), dx.data_ptr(), N, Hh * Ww, C, H.stream())
+        return dx
 
 
 # =====================================================================================================

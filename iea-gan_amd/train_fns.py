@@ -40,7 +40,8 @@ def _clip(net, max_norm):
 
 
 def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
-    contra_criter = loss.Conditional_Contrastive_loss(device, config["batch_size"], config["pos_collected_numerator"])
+    if config["pos_collected_numerator"]:
+        raise NotImplementedError("pos_collected_numerator=True is not part of the MI355X path (reference default: False)")
     bs = config["batch_size"]
     sync = parallel.get_context()
     if sync is not None:
@@ -114,20 +115,21 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
                         D_fake, D_real = outs
                         if config["Con_reg"]:
                             aug_out = (None, D(xa[counter], ys[counter]))
-                D_loss_real, D_loss_fake = loss.loss_hinge_dis(D_fake, D_real)
-                D_loss = D_loss_real + D_loss_fake
-                if contra and config["contra_lambda"] != 0:
-                    mask = utils.make_mask(ys[counter], config["n_classes"], device) if config["pos_collected_numerator"] else None
-                    D_loss = D_loss + config["contra_lambda"] * contra_criter(cls_embed_real, cls_proxies_real, mask,
-                                                                             ys[counter], t, 0)
+                # every D-phase loss term in ONE fused launch (value + gradient): hinge real/fake, 2C, uniformity
+                use_c = contra and config["contra_lambda"] != 0
+                use_u = contra and config["Uniformity_loss"]
+                D_loss, terms = ops.loss_block(dfake=D_fake, dreal=D_real, e=cls_embed_real if (use_c or use_u) else None,
+                                               p=cls_proxies_real if use_c else None, w_hinge_real=1.0, w_hinge_fake=1.0,
+                                               w_contra=config["contra_lambda"] if use_c else 0.0,
+                                               w_unif=config["unif_lambda"] if use_u else 0.0, temperature=t)
+                D_loss_real, D_loss_fake = terms[1], terms[2]
+                if use_u:
+                    unif_loss_d = terms[5]
                 if aug_out is not None:
                     consistency = loss.l2_loss(D_real, aug_out[1])
                     if aug_out[0] is not None:
                         consistency = consistency + loss.l2_loss(cls_embed_real, aug_out[0])
                     D_loss = D_loss + config["cr_lambda"] * consistency
-                if contra and config["Uniformity_loss"]:
-                    unif_loss_d = loss.unif_loss(cls_embed_real)
-                    D_loss = D_loss + config["unif_lambda"] * unif_loss_d
                 with ops.direct_grads():
                     (D_loss / float(config["num_D_accumulations"])).backward()
             if config["D_ortho"] > 0.0:
@@ -145,20 +147,22 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
             if contra:
                 cls_proxies_fake, cls_embed_fake, D_fake = GD(z_, ys[counter], x_aug=None, contra=True, train_G=True,
                                                              split_D=config["split_D"], diff_aug=config["diff_aug"])
-                G_loss = loss.loss_hinge_gen(D_fake)
-                if config["contra_lambda"] != 0:
-                    mask = utils.make_mask(ys[counter], config["n_classes"], device) if config["pos_collected_numerator"] else None
-                    G_loss = G_loss + config["contra_lambda"] * contra_criter(cls_embed_fake, cls_proxies_fake, mask,
-                                                                             ys[counter], t, 0)
-                if config["IEA_loss"]:
-                    iea_loss = loss.IEA_loss(cls_embed_fake, cls_embed_real.detach())
-                    G_loss = G_loss + config["IEA_lambda"] * iea_loss
-                    if config["Uniformity_loss"]:      # nested under IEA_loss, as in the reference (:171-178)
-                        G_loss = G_loss + config["unif_lambda"] * loss.unif_loss(cls_embed_fake)
+                use_c = config["contra_lambda"] != 0
+                use_i = bool(config["IEA_loss"])
+                use_u = use_i and bool(config["Uniformity_loss"])      # nested under IEA_loss, as in the reference (:171-178)
+                need_e = use_c or use_i or use_u
+                G_loss, terms = ops.loss_block(dfake=D_fake, e=cls_embed_fake if need_e else None,
+                                               p=cls_proxies_fake if use_c else None,
+                                               er=cls_embed_real.detach() if use_i else None, w_hinge_gen=1.0,
+                                               w_contra=config["contra_lambda"] if use_c else 0.0,
+                                               w_unif=config["unif_lambda"] if use_u else 0.0,
+                                               w_iea=config["IEA_lambda"] if use_i else 0.0, temperature=t)
+                if use_i:
+                    iea_loss = terms[6]
             else:
                 D_fake = GD(z_, y_, x_aug=None, contra=False, train_G=True, split_D=config["split_D"],
                             diff_aug=config["diff_aug"])
-                G_loss = loss.loss_hinge_gen(D_fake)
+                G_loss = loss.loss_hinge_gen(D_fake.reshape(-1))
             G_loss = G_loss / float(config["num_G_accumulations"])
             with ops.direct_grads():
                 G_loss.backward()
@@ -203,8 +207,10 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
             graph["x"], graph["y"] = x.clone(), y.clone()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
+            ops.reset_zero_pool()              # every zero-filled scratch chunk of the step must be filled INSIDE the graph
             with torch.cuda.graph(g):
                 graph["out"] = step(graph["x"], graph["y"])
+            ops.reset_zero_pool()              # ... and eager code must never carve from graph-owned memory
             graph["g"] = g
         graph["x"].copy_(x)
         graph["y"].copy_(y)

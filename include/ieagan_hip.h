@@ -130,6 +130,21 @@ int ieagan_nl_attention_fwd(const void* Q, const void* K, const void* V, void* O
 int ieagan_nl_attention_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
                             float* delta, void* dQ, void* dK, void* dV, int N, int Lq, int Lk, int dqk, int dv, void* stream);
 
+/* ---- small single-workgroup kernels (small_ops.hip) --------------------------------------------------
+ * RRM attention core: softmax(q k^T / sqrt(hd)) v per (batch, head), S <= 64 tokens, affinity in LDS
+ * (RRM.py:10-16, 46-58).  qkv [B,S,H,3*hd] (packed projection), out [B,S,H*hd], att [B,H,S,S], all fp32. */
+int ieagan_rrm_attention_fwd(const float* qkv, float* out, float* att, int B, int S, int H, int hd, void* stream);
+int ieagan_rrm_attention_bwd(const float* qkv, const float* att, const float* dout, float* dqkv, int B, int S, int H, int hd,
+                             void* stream);
+/* all losses of one phase, value and gradient, one launch (loss.py:8-44, 79-132); weights6 (host) = weights of
+ * {hinge_real, hinge_fake, hinge_gen, contrastive, uniformity, IEA}; vals8 (device) = {total, the six terms, 0} */
+int ieagan_loss_block(const float* dfake, const float* dreal, const float* e, const float* p, const float* er,
+                      const float* weights6, float temperature, float* vals8, float* g_dfake, float* g_dreal, float* g_e,
+                      float* g_p, int n, int d, void* stream);
+/* D head: global sum pool of relu(h) (model.py:912) */
+int ieagan_relu_sum_pool(const void* x, float* out, int N, int HW, int C, void* stream);
+int ieagan_relu_sum_pool_bwd(const void* x, const float* dh, void* dx, int N, int HW, int C, void* stream);
+
 /* ---- augmentation + optimiser (aug_optim.hip) -------------------------------------------------- */
 int ieagan_diffaug_fwd(const float* x, const float* bright, const float* contrast, const long* tx, const long* ty,
                        const long* ox, const long* oy, float* sums, float* out, int N, int H, int W, void* stream);

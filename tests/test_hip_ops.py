@@ -396,3 +396,50 @@ def test_nl_attention_forward_backward(dev, N, Lq, Lk, dqk, dv):
     g = torch.autograd.grad((out.float() * go).sum(), [q2, k2, v2])
     for nme, a, b in zip(("dq", "dk", "dv"), g, gref):
         close(a, b, 3e-2, f"attention {nme}")
+
+
+def test_loss_block_vs_golden(dev, golden_dir):
+    """Fused loss kernel against the reference-generated values and gradients (loss.py)."""
+    import loss as L
+    import ops
+    g = np.load(os.path.join(golden_dir, "op_losses.npz"))
+    t = lambda k: torch.from_numpy(g[k]).to(dev)
+    e, p = t("e").requires_grad_(True), t("p").requires_grad_(True)
+    crit = L.Conditional_Contrastive_loss(dev, 40, False)
+    vals = {"contra": crit(e, p, None, None, 1.0, 0), "unif": L.unif_loss(e), "iea": L.IEA_loss(e, t("e2")),
+            "hinge_real": L.loss_hinge_dis(t("dfk"), t("drl"))[0], "hinge_fake": L.loss_hinge_dis(t("dfk"), t("drl"))[1],
+            "hinge_gen": L.loss_hinge_gen(t("dfk"))}
+    for k, v in vals.items():
+        ref = float(g[k])
+        assert abs(float(v) - ref) <= 2e-5 * max(1.0, abs(ref)) + 1e-6, (k, float(v), ref)
+    # one fused call for contra + 0.1 unif + iea: value and both gradients
+    total, terms = ops.loss_block(e=e, p=p, er=t("e2"), w_contra=1.0, w_unif=0.1, w_iea=1.0)
+    ge, gp = torch.autograd.grad(total, [e, p])
+    close(ge, t("g_e"), 1e-4, "d total / d e")
+    close(gp, t("g_p"), 1e-4, "d total / d p")
+    # hinge gradients
+    dfk, drl = t("dfk").requires_grad_(True), t("drl").requires_grad_(True)
+    tot, _ = ops.loss_block(dfake=dfk, dreal=drl, w_hinge_real=1.0, w_hinge_fake=1.0)
+    gf, gr = torch.autograd.grad(tot, [dfk, drl])
+    rf, rr = torch.autograd.grad(torch.relu(1 + dfk).mean() + torch.relu(1 - drl).mean(), [dfk, drl])
+    close(gf, rf, 1e-6, "hinge d fake")
+    close(gr, rr, 1e-6, "hinge d real")
+
+
+@pytest.mark.parametrize("E,heads", [(128, 2), (512, 4)])
+def test_rrm_attention_core(dev, E, heads):
+    import ops
+    torch.manual_seed(13)
+    B, S = 1, 40
+    hd = E // heads
+    qkv = torch.randn(B, S, 3 * E, device=dev, requires_grad=True)
+    go = torch.randn(B, S, E, device=dev)
+    q, k, v = qkv.reshape(B, S, heads, 3 * hd).permute(0, 2, 1, 3).chunk(3, dim=-1)
+    ref = (torch.softmax(q @ k.transpose(-2, -1) / math.sqrt(hd), -1) @ v).permute(0, 2, 1, 3).reshape(B, S, E)
+    (gref,) = torch.autograd.grad(ref, [qkv], go)
+    qkv2 = qkv.detach().clone().requires_grad_(True)
+    out, att = ops.RRMAttentionFn.apply(qkv2, heads)
+    close(out, ref, 1e-5, "rrm attention out")
+    (g2,) = torch.autograd.grad(out, [qkv2], go)
+    close(g2, gref, 1e-4, "rrm attention grad")
+    assert att.shape == (B, heads, S, S) and torch.allclose(att.sum(-1), torch.ones(B, heads, S, device=dev), atol=1e-5)
