@@ -46,5 +46,6 @@ def default_config() -> dict:
              load_optim=True)
     # -- keys that exist only here (defaults = reference behaviour)
     c.update(strict_reference=True,      # keep the reference's call order / quirks
-             events_per_step=1)          # E independent events batched per GPU (config 4), 1 = reference
+             events_per_step=1,          # E independent events batched per GPU (config 4), 1 = reference
+             hip_graph=False)            # replay the whole train step as one captured HIP graph (single GPU)
     return c

@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""Training entry point of the MI355X IEA-GAN path.
+
+Keeps the reference's control flow (reference ``train.py``: run 22-247, main 250-259, epoch loop 158-173):
+defaults <- ``config.json`` (optional) <- command line, build G / D / G_ema / G_D, ``utils.prepare_z_y``,
+``train_fns.GAN_training_function``, then per iteration ``G.train(); D.train(); metrics = train(x, y)``,
+metric / singular-value logging and periodic checkpoints in the reference's file layout.
+
+Data: ``--dataroot DIR`` with one ``*.npy`` per event (uint8 ``[40, 250, 768]`` detector images, or float32
+already in [-1, 1]); the pad(3 rows) -> lognorm255 -> +4e-3 U dequantisation -> [-1, 1] chain of the
+reference's loader (utils/dataloader.py:59-76, utils/norm.py:8-19) runs on the GPU.  ``--synthetic N`` trains on
+N generated events (no files).  Any default of ``defaults.default_config()`` can be overridden as ``--key value``.
+Multi-GPU: launch with ``python -m torch.distributed.run --nproc-per-node N train.py ...`` (events are sharded
+over the ranks, gradients all-reduced over RCCL).
+"""
+from __future__ import annotations
+
+import argparse
+import glob
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import model          # noqa: E402
+import parallel       # noqa: E402
+import train_fns      # noqa: E402
+import utils          # noqa: E402
+from defaults import default_config      # noqa: E402
+
+
+def parse(argv):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--config", default=None, help="json file with overrides (the reference's config.json works)")
+    ap.add_argument("--dataroot", default=None)
+    ap.add_argument("--synthetic", type=int, default=0, help="train on this many generated events instead of files")
+    ap.add_argument("--outputroot", default="runs")
+    ap.add_argument("--device", default="cuda")
+    ap.add_argument("--max_iters", type=int, default=0, help="stop after this many iterations (0: run num_epochs)")
+    args, rest = ap.parse_known_args(argv)
+    cfg = default_config()
+    if args.config:
+        cfg.update(json.load(open(args.config)))
+    it = iter(rest)
+    for tok in it:        # generic --key value overrides, typed after the default
+        if not tok.startswith("--"):
+            raise SystemExit(f"unexpected argument {tok}")
+        key = tok[2:]
+        if key not in cfg:
+            raise SystemExit(f"unknown option --{key}")
+        cur = cfg[key]
+        if isinstance(cur, bool):
+            nxt = next(it, "true")
+            cfg[key] = nxt.lower() in ("1", "true", "yes")
+        else:
+            val = next(it)
+            cfg[key] = None if val.lower() in ("none", "null") else (type(cur)(val) if cur is not None else json.loads(val))
+    cfg.update(device=args.device, dataroot=args.dataroot, outputroot=args.outputroot, synthetic=args.synthetic,
+               max_iters=args.max_iters)
+    return cfg
+
+
+def synthetic_event(n, h, w, seed):
+    rng = np.random.Generator(np.random.PCG64([seed, 77]))
+    hit = rng.random((n, h, w)) < 0.01
+    adc = np.where(hit, rng.uniform(8, 255, (n, h, w)), 0.0)
+    return adc.astype(np.uint8)
+
+
+def to_network_range(ev: torch.Tensor, res_h: int) -> torch.Tensor:
+    """uint8 [40, 250(+), W] ADC counts -> float32 [40, 1, res_h, W] in [-1, 1] (pad, lognorm255, noise, normalise)."""
+    x = ev.float()
+    if ev.dtype == torch.uint8:
+        x = x / 255.0
+        pad = res_h - x.shape[1]
+        if pad > 0:
+            x = torch.nn.functional.pad(x, (0, 0, pad // 2, pad - pad // 2))
+        x = torch.log(255.0 * x + 1.0) / math.log(256.0)
+        x = x + 4e-3 * torch.rand_like(x)
+        x = (x - 0.5) / 0.5
+    return x.unsqueeze(1).contiguous()
+
+
+def run(cfg):
+    rank, world, local = parallel.init_from_env()
+    if world > 1:
+        parallel.set_context(parallel.GradSync(overlap=True))
+    dev = torch.device(cfg["device"], local) if cfg["device"] == "cuda" else torch.device(cfg["device"])
+    utils.seed_rng(cfg["seed"] + rank)
+    G = model.Generator(**cfg).to(dev)
+    D = model.Discriminator(**cfg).to(dev)
+    G_ema = ema = None
+    if cfg["ema"]:
+        G_ema = model.Generator(**dict(cfg, skip_init=True, no_optim=True)).to(dev)
+        ema = utils.apply_ema(G, G_ema, cfg["ema_decay"], cfg["ema_start"])
+    GD = model.G_D(G, D)
+    state = {"itr": 0, "epoch": 0, "save_num": 0, "best_FID": 999999, "config": cfg}
+    name = cfg["run_name"]
+    wroot, lroot = os.path.join(cfg["outputroot"], "weights"), os.path.join(cfg["outputroot"], "logs")
+    if cfg["resume"]:
+        utils.load_weights(G, D, state, wroot, name, None, G_ema, load_optim=cfg["load_optim"])
+    if world > 1:
+        for net in (G, D):
+            net._prepare()
+            parallel.broadcast_flat(net._arena.flat)
+    utils.count_parameters(G)
+    utils.count_parameters(D)
+    if rank == 0:
+        utils.write_metadata(lroot, name, {k: v for k, v in cfg.items()}, {k: v for k, v in state.items() if k != "config"})
+    h, w = cfg["resolution"], cfg["resolution"] * cfg["H_base"]
+    if cfg["synthetic"]:
+        events = [synthetic_event(cfg["n_classes"], h - 6, w, cfg["seed"] + i) for i in range(cfg["synthetic"])]
+    else:
+        files = sorted(glob.glob(os.path.join(cfg["dataroot"] or "", "*.npy")))
+        if not files:
+            raise SystemExit("no *.npy events under --dataroot (or use --synthetic N)")
+        events = files
+    mine = [events[i] for i in parallel.shard_events(len(events), rank, world)]
+    z_, y_ = utils.prepare_z_y(max(cfg["G_batch_size"], cfg["batch_size"]), G.dim_z, cfg["n_classes"], device=dev,
+                               z_dist=cfg["z_dist"], threshold=cfg["truncated_threshold"])
+    train = train_fns.GAN_training_function(G, D, GD, z_, y_, ema, state, cfg, dev)
+    y = torch.arange(cfg["n_classes"], device=dev)
+    log = open(os.path.join(lroot, name, f"metrics_rank{rank}.jsonl"), "a") if rank == 0 else None
+    t0 = time.time()
+    for epoch in range(state["epoch"], cfg["num_epochs"]):
+        order = np.random.permutation(len(mine)) if cfg["shuffle"] else np.arange(len(mine))
+        for i in order:
+            state["itr"] += 1
+            G.train()
+            D.train()
+            if G_ema is not None:
+                G_ema.train()
+            ev = mine[i] if isinstance(mine[i], np.ndarray) else np.load(mine[i])
+            x = to_network_range(torch.from_numpy(ev).to(dev), h)
+            metrics = train(x, y)
+            if log is not None:
+                rec = dict(itr=state["itr"], **metrics)
+                if state["itr"] % cfg["sv_log_interval"] == 0:
+                    rec.update(utils.get_singular_values(G, "G"))
+                    rec.update(utils.get_singular_values(D, "D"))
+                log.write(json.dumps(rec) + "\n")
+                log.flush()
+            if state["itr"] % cfg["log_interval"] == 0 and rank == 0:
+                print(f"itr {state['itr']}  {(time.time() - t0) / state['itr']:.3f} s/itr  " +
+                      "  ".join(f"{k} {v:.4f}" for k, v in metrics.items()))
+            if state["itr"] % cfg["save_every"] == 0 and rank == 0:
+                utils.save_weights(G, D, {k: v for k, v in state.items() if k != "config"}, wroot, name, None, G_ema)
+            if cfg["max_iters"] and state["itr"] >= cfg["max_iters"]:
+                break
+        state["epoch"] += 1
+        if cfg["max_iters"] and state["itr"] >= cfg["max_iters"]:
+            break
+    if rank == 0:
+        utils.save_weights(G, D, {k: v for k, v in state.items() if k != "config"}, wroot, name, None, G_ema)
+        print(f"done: {state['itr']} iterations, weights under {os.path.join(wroot, name)}")
+    return state
+
+
+def main(argv=None):
+    run(parse(sys.argv[1:] if argv is None else argv))
+
+
+if __name__ == "__main__":
+    main()

@@ -145,3 +145,78 @@ def ortho(model, strength=1e-4, blacklist=None):
 
 def count_parameters(module):
     print("Number of parameters: {}".format(sum(p.data.nelement() for p in module.parameters())))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# checkpoint I/O and singular-value logging: the reference's file layout
+# {G, G_optim, D, D_optim, state_dict, G_ema}[_suffix].pth (utils/__init__.py:689-726, 592-668)
+# ---------------------------------------------------------------------------------------------------------
+def _ckpt_name(root, experiment_name, stem, suffix):
+    import os
+    return os.path.join(root, experiment_name, f"{stem}_{suffix}.pth" if suffix else f"{stem}.pth")
+
+
+def save_weights(G, D, state_dict, weights_root, experiment_name, name_suffix=None, G_ema=None):
+    import os
+    os.makedirs(os.path.join(weights_root, experiment_name), exist_ok=True)
+    clone = lambda sd: {k: v.detach().clone().cpu() for k, v in sd.items()}     # detach the views from the flat arena
+    torch.save(clone(G.state_dict()), _ckpt_name(weights_root, experiment_name, "G", name_suffix))
+    torch.save(G.optim.state_dict(), _ckpt_name(weights_root, experiment_name, "G_optim", name_suffix))
+    torch.save(clone(D.state_dict()), _ckpt_name(weights_root, experiment_name, "D", name_suffix))
+    torch.save(D.optim.state_dict(), _ckpt_name(weights_root, experiment_name, "D_optim", name_suffix))
+    torch.save(state_dict, _ckpt_name(weights_root, experiment_name, "state_dict", name_suffix))
+    if G_ema is not None:
+        torch.save(clone(G_ema.state_dict()), _ckpt_name(weights_root, experiment_name, "G_ema", name_suffix))
+
+
+def _rename_legacy(sd):
+    """Checkpoints of older reference revisions call the RRMs ``transG`` / ``transcoder`` (utils/__init__.py:242-258)."""
+    return {k.replace("transG", "RR_G").replace("transcoder", "RR_D"): v for k, v in sd.items()}
+
+
+def load_weights(G, D, state_dict, weights_root, experiment_name, name_suffix=None, G_ema=None, strict=True, load_optim=True):
+    def load(net, stem):
+        sd = torch.load(_ckpt_name(weights_root, experiment_name, stem, name_suffix), map_location="cpu")
+        try:
+            net.load_state_dict(sd, strict=strict)
+        except RuntimeError:
+            net.load_state_dict(_rename_legacy(sd), strict=strict)
+    if G is not None:
+        load(G, "G")
+        if load_optim:
+            try:
+                G.optim.load_state_dict(torch.load(_ckpt_name(weights_root, experiment_name, "G_optim", name_suffix)))
+            except (ValueError, FileNotFoundError):
+                print("G optimizer state not loaded (a reference-format Adam checkpoint does not map onto the flat arena)")
+    if D is not None:
+        load(D, "D")
+        if load_optim:
+            try:
+                D.optim.load_state_dict(torch.load(_ckpt_name(weights_root, experiment_name, "D_optim", name_suffix)))
+            except (ValueError, FileNotFoundError):
+                print("D optimizer state not loaded")
+    for k, v in torch.load(_ckpt_name(weights_root, experiment_name, "state_dict", name_suffix)).items():
+        state_dict[k] = v
+    if G_ema is not None:
+        load(G_ema, "G_ema")
+
+
+def get_singular_values(net, prefix):
+    """{'<prefix>_<layer>_SV0': sigma} for every spectrally normalised layer, with ONE device-to-host copy
+    (the reference does one ``.item()`` per layer: ~211 host syncs every sv_log_interval iterations)."""
+    names, vals = [], []
+    for k, v in net.state_dict().items():
+        if k.endswith(".sv0") or k == "sv0":
+            names.append(k)
+            vals.append(v.reshape(-1)[:1])
+    if not names:
+        return {}
+    host = torch.cat(vals).float().cpu().tolist()
+    return {f"{prefix}_{n[:-4].replace('.', '_')}_SV0": float(x) for n, x in zip(names, host)}
+
+
+def write_metadata(logs_root, experiment_name, config, state_dict):
+    import datetime, os
+    os.makedirs(os.path.join(logs_root, experiment_name), exist_ok=True)
+    with open(os.path.join(logs_root, experiment_name, "metalog.txt"), "w") as f:
+        f.write(f"datetime: {datetime.datetime.now()}\nconfig: {config}\nstate: {state_dict}\n")

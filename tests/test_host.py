@@ -123,3 +123,19 @@ def test_data_parallel_grad_sync_gloo_world2(tmp_path):
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2, r.stdout + r.stderr
+
+
+def test_train_entry_point_config_merge(tmp_path):
+    """defaults <- config.json <- command line, typed after the defaults (the reference's SUPPRESS-style merge)."""
+    import json as _json
+    import train
+    cfgfile = tmp_path / "config.json"
+    cfgfile.write_text(_json.dumps({"G_lr": 1e-4, "resolution": 128}))
+    cfg = train.parse(["--config", str(cfgfile), "--synthetic", "3", "--resolution", "64", "--H_base", "1", "--clip_norm", "1e9",
+                       "--ema", "false", "--max_iters", "2", "--device", "cuda"])
+    assert cfg["resolution"] == 64 and cfg["H_base"] == 1 and cfg["G_lr"] == 1e-4 and cfg["clip_norm"] == 1e9
+    assert cfg["ema"] is False and cfg["synthetic"] == 3 and cfg["D_lr"] == 5e-5
+    x = train.to_network_range(torch.from_numpy(train.synthetic_event(40, 58, 64, 1)), 64)
+    assert x.shape == (40, 1, 64, 64) and x.min() >= -1.0 and x.max() <= 1.01
+    with pytest.raises(SystemExit):
+        train.parse(["--no_such_option", "1"])
