@@ -107,7 +107,8 @@ def main():
     dev = torch.device("cuda", local)
     cfg = bench_config()
     cfg["resolution"] = args.resolution
-    cfg["hip_graph"] = (world == 1) and not args.no_graph
+    cfg["hip_graph"] = not args.no_graph
+    force_dp = bool(os.environ.get("IEAGAN_FORCE_DP")) and dist.is_initialized()     # 1-rank rehearsal of the DP path
     if args.resolution != 256:
         cfg["H_base"] = 1
     utils.seed_rng(cfg["seed"])
@@ -117,8 +118,8 @@ def main():
         G_ema = model.Generator(**dict(cfg, skip_init=True, no_optim=True)).to(dev)
         ema = utils.apply_ema(G, G_ema, cfg["ema_decay"], cfg["ema_start"])
     GD = model.G_D(G, D)
-    if world > 1:
-        parallel.set_context(parallel.GradSync(overlap=True))
+    if world > 1 or force_dp:
+        parallel.set_context(parallel.GradSync(overlap=True, force=force_dp))
         for net in (G, D):
             net._prepare()
             parallel.broadcast_flat(net._arena.flat)

@@ -22,10 +22,11 @@ class GradSync:
     """All-reduce-mean of one flat gradient buffer followed by a callback (the optimiser step),
     optionally on a side stream.  Works on CPU tensors with gloo (tests) and on HIP with RCCL."""
 
-    def __init__(self, group=None, overlap=True):
+    def __init__(self, group=None, overlap=True, force=False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.overlap = overlap
+        self.force = force and dist.is_initialized()      # exercise the collective path with a 1-rank group (tests)
         self._stream = None
         self._pending = {}
 
@@ -34,14 +35,14 @@ class GradSync:
             self._stream = torch.cuda.Stream()
         return self._stream
 
-    def reduce_then(self, key, flat_grad: torch.Tensor, then=None):
-        """Average ``flat_grad`` over the ranks, then call ``then()``.  On HIP with overlap the work is
-        enqueued on a side stream and ``wait(key)`` must be called before the results are consumed."""
-        if self.world == 1:
+    def reduce_then(self, key, flat_grad: torch.Tensor, then=None, blocking=False):
+        """Average ``flat_grad`` over the ranks, then call ``then()``.  On HIP with overlap (and not ``blocking``)
+        the work is enqueued on a side stream and ``wait(key)`` must be called before the results are consumed."""
+        if self.world == 1 and not self.force:
             if then is not None:
                 then()
             return
-        if flat_grad.is_cuda and self.overlap:
+        if flat_grad.is_cuda and self.overlap and not blocking:
             ev = torch.cuda.Event()
             ev.record()
             side = self._side_stream()
@@ -86,7 +87,7 @@ def shard_events(n_events: int, rank: int, world: int):
 def init_from_env(backend=None):
     """Initialise torch.distributed from the torchrun environment (RANK / WORLD_SIZE / MASTER_*)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    if world <= 1 and not (os.environ.get("IEAGAN_FORCE_DP") and "RANK" in os.environ):
         return 0, 1, 0
     rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
     if backend is None:

@@ -226,3 +226,19 @@ def test_train_entry_point_and_checkpoint_round_trip(tmp_path):
     ref = torch.load(os.path.join(wdir, "G.pth"))
     assert st["itr"] == 3 and all(torch.equal(G.state_dict()[k].cpu(), v) for k, v in ref.items())
     assert int(G.optim.state_dict()["step"]) == 3
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_data_parallel_path_single_rank_rehearsal(graph):
+    """The data-parallel code path (side-stream all-reduce + Adam, pre-forward waits, segmented HIP graphs) with a
+    1-rank RCCL group on this GPU: bench.py must run and report finite losses."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IEAGAN_FORCE_DP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29531")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29531", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "3",
+           "--no-cpu-baseline", "--no-kernel-timing", "--resolution", "64"] + ([] if graph else ["--no-graph"])
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec["n_gpus"] == 1 and rec["value"] > 0 and all(np.isfinite(v) for v in rec["losses_last_step"].values()), rec
