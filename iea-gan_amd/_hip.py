@@ -77,6 +77,12 @@ _SIGS = {
     "ieagan_cr_diffaug": [vp, vp, vp, vp, vp, i, i, i, vp],
     "ieagan_adam_step": [vp, vp, vp, vp, l, vp, vp],
     "ieagan_ema_update": [vp, vp, l, vp, vp],
+    "ieagan_maxpool2_fwd": [vp, vp, vp, i, i, i, i, vp],
+    "ieagan_maxpool2_bwd": [vp, vp, vp, i, i, i, i, vp],
+    "ieagan_gamma_residual_fwd": [vp, vp, vp, vp, l, vp],
+    "ieagan_gamma_residual_bwd": [vp, vp, vp, vp, vp, l, vp],
+    "ieagan_ortho_ksplit": [],
+    "ieagan_ortho_grad": [vp, vp, vp, vp, i, vp, i, vp, l, f, vp],
     "ieagan_selftest_tr_read": [vp, vp, vp],
 }
 EXPORTS = ["ieagan_last_error"] + list(_SIGS)

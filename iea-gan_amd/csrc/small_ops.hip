@@ -446,3 +446,149 @@ extern "C" int ieagan_relu_sum_pool_bwd(const void* x, const float* dh, void* dx
     CHECK_LAUNCH("relu_sum_pool_bwd");
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Non-local block glue (layers.py:276-300): 2x2 max-pool of phi / g on bf16 NHWC maps (argmax kept as one byte per
+// output element, first maximum in window scan order like F.max_pool2d) and out = gamma * o + x with a device scalar
+// gamma; backward d_o = gamma * d, dgamma = sum(d * o) (dx is d itself).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const bf16x8* __restrict__ x, bf16x8* __restrict__ out, uint64_t* __restrict__ idx,
+                                                           long total, int Ho, int Wo, int C8) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C8);
+        long t = i / C8;
+        const int wo = (int)(t % Wo);
+        t /= Wo;
+        const int ho = (int)(t % Ho);
+        const long n = t / Ho;
+        const long W = 2L * Wo;
+        const long base = ((n * 2 * Ho + 2 * ho) * W + 2 * wo) * C8 + c;
+        const bf16x8 v0 = x[base], v1 = x[base + C8], v2 = x[base + W * C8], v3 = x[base + W * C8 + C8];
+        bf16x8 m;
+        uint64_t sel = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float best = bf2f(v0[j]);
+            unsigned k = 0;
+            float a = bf2f(v1[j]);
+            if (a > best || a != a) { best = a; k = 1; }
+            a = bf2f(v2[j]);
+            if (a > best || a != a) { best = a; k = 2; }
+            a = bf2f(v3[j]);
+            if (a > best || a != a) { best = a; k = 3; }
+            m[j] = f2bf(best);
+            sel |= (uint64_t)k << (8 * j);
+        }
+        out[i] = m;
+        idx[i] = sel;
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const bf16x8* __restrict__ dout, const uint64_t* __restrict__ idx,
+                                                           bf16x8* __restrict__ dx, long total, int Ho, int Wo, int C8) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C8);
+        long t = i / C8;
+        const int wo = (int)(t % Wo);
+        t /= Wo;
+        const int ho = (int)(t % Ho);
+        const long n = t / Ho;
+        const long W = 2L * Wo;
+        const long base = ((n * 2 * Ho + 2 * ho) * W + 2 * wo) * C8 + c;
+        const bf16x8 d = dout[i];
+        const uint64_t sel = idx[i];
+        bf16x8 o[4] = {zero8(), zero8(), zero8(), zero8()};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned k = (unsigned)(sel >> (8 * j)) & 3u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (k == (unsigned)q) o[q][j] = d[j];
+        }
+        dx[base] = o[0];
+        dx[base + C8] = o[1];
+        dx[base + W * C8] = o[2];
+        dx[base + W * C8 + C8] = o[3];
+    }
+}
+
+__global__ __launch_bounds__(256) void gamma_residual_fwd_kernel(const bf16x8* __restrict__ o, const bf16x8* __restrict__ x,
+                                                                 const float* __restrict__ gamma, bf16x8* __restrict__ out, long total8) {
+    const float g = gamma[0];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long)gridDim.x * 256) {
+        const bf16x8 a = o[i], b = x[i];
+        bf16x8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = f2bf(fmaf(g, bf2f(a[j]), bf2f(b[j])));
+        out[i] = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void gamma_residual_bwd_kernel(const bf16x8* __restrict__ d, const bf16x8* __restrict__ o,
+                                                                 const float* __restrict__ gamma, bf16x8* __restrict__ d_o,
+                                                                 float* __restrict__ dgamma, long total8) {
+    __shared__ float red[4];
+    const float g = gamma[0];
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long)gridDim.x * 256) {
+        const bf16x8 dv = d[i], ov = o[i];
+        bf16x8 r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float df = bf2f(dv[j]);
+            acc = fmaf(df, bf2f(ov[j]), acc);
+            r[j] = f2bf(g * df);
+        }
+        d_o[i] = r;
+    }
+    acc = block_reduce_sum(acc, red);
+    if (threadIdx.x == 0) atomicAdd(&dgamma[blockIdx.x % STAT_REPL], acc);
+}
+
+static inline unsigned ew_blocks(long total) {
+    long b = (total + 255) / 256;
+    return (unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+extern "C" int ieagan_maxpool2_fwd(const void* x, void* out, void* idx, int N, int H, int W, int C, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    CHECK_ARG(C % 8 == 0 && H % 2 == 0 && W % 2 == 0 && N > 0, "maxpool2: need C %% 8 == 0 and even H, W (got C=%d H=%d W=%d)", C, H, W);
+    const long total = (long)N * (H / 2) * (W / 2) * (C / 8);
+    ProfScope prof("maxpool2_fwd", 0.0, total * (64.0 + 16.0 + 8.0), st);
+    hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, (const bf16x8*)x, (bf16x8*)out, (uint64_t*)idx, total,
+                       H / 2, W / 2, C / 8);
+    CHECK_LAUNCH("maxpool2_fwd");
+    return 0;
+}
+
+extern "C" int ieagan_maxpool2_bwd(const void* dout, const void* idx, void* dx, int N, int H, int W, int C, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    CHECK_ARG(C % 8 == 0 && H % 2 == 0 && W % 2 == 0 && N > 0, "maxpool2_bwd: need C %% 8 == 0 and even H, W (got C=%d H=%d W=%d)", C, H, W);
+    const long total = (long)N * (H / 2) * (W / 2) * (C / 8);
+    ProfScope prof("maxpool2_bwd", 0.0, total * (64.0 + 16.0 + 8.0), st);
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, (const bf16x8*)dout, (const uint64_t*)idx, (bf16x8*)dx,
+                       total, H / 2, W / 2, C / 8);
+    CHECK_LAUNCH("maxpool2_bwd");
+    return 0;
+}
+
+extern "C" int ieagan_gamma_residual_fwd(const void* o, const void* x, const float* gamma, void* out, long n, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    CHECK_ARG(n % 8 == 0 && n > 0 && gamma, "gamma_residual: element count must be a positive multiple of 8 (got %ld)", n);
+    ProfScope prof("gamma_residual_fwd", 2.0 * n, 6.0 * n, st);
+    hipLaunchKernelGGL(gamma_residual_fwd_kernel, dim3(ew_blocks(n / 8)), dim3(256), 0, st, (const bf16x8*)o, (const bf16x8*)x, gamma,
+                       (bf16x8*)out, n / 8);
+    CHECK_LAUNCH("gamma_residual_fwd");
+    return 0;
+}
+
+/* dgamma: STAT_REPL floats, zeroed by the caller; the caller folds them. */
+extern "C" int ieagan_gamma_residual_bwd(const void* d, const void* o, const float* gamma, void* d_o, float* dgamma, long n, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    CHECK_ARG(n % 8 == 0 && n > 0 && gamma && dgamma, "gamma_residual_bwd: element count must be a positive multiple of 8 (got %ld)", n);
+    ProfScope prof("gamma_residual_bwd", 3.0 * n, 6.0 * n, st);
+    hipLaunchKernelGGL(gamma_residual_bwd_kernel, dim3(ew_blocks(n / 8)), dim3(256), 0, st, (const bf16x8*)d, (const bf16x8*)o, gamma,
+                       (bf16x8*)d_o, dgamma, n / 8);
+    CHECK_LAUNCH("gamma_residual_bwd");
+    return 0;
+}

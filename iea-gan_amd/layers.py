@@ -163,22 +163,19 @@ class Attention(nn.Module):
 
     def fused(self, xa, recs, prefix):
         """xa: bf16 [N,H,W,C].  theta/phi/g/o 1x1 convs and the streaming-softmax affinity are HIP kernels;
-        the 2x2 max-pool of phi / g and the final gamma*o + x are small library element-wise ops."""
+        the 2x2 max-pool of phi / g and the final gamma*o + x are two small HIP element-wise kernels."""
         N, Hh, Ww, C = xa.shape
         theta, _ = self.theta.fused(xa, recs[prefix + ".theta"])
         phi, _ = self.phi.fused(xa, recs[prefix + ".phi"])
         g, _ = self.g.fused(xa, recs[prefix + ".g"])
 
-        def pool(t):   # NHWC tensor viewed as channels_last NCHW -> 2x2 max pool -> NHWC
-            return F.max_pool2d(t.permute(0, 3, 1, 2), [2, 2]).permute(0, 2, 3, 1).contiguous()
-
-        phi, g = pool(phi), pool(g)
+        phi, g = ops.MaxPool2Fn.apply(phi), ops.MaxPool2Fn.apply(g)
         q = theta.view(N, Hh * Ww, C // 8)
         k = phi.view(N, Hh * Ww // 4, C // 8)
         v = g.view(N, Hh * Ww // 4, C // 2)
         o_pre = ops.NLAttentionFn.apply(q, k, v).view(N, Hh, Ww, C // 2)
         o, _ = self.o.fused(o_pre, recs[prefix + ".o"])
-        return (self.gamma * o.float() + xa.float()).to(xa.dtype)
+        return ops.GammaResidualFn.apply(o, xa, self.gamma)
 
     def forward(self, x, y=None):
         H.require_gpu()

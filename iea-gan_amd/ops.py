@@ -782,6 +782,52 @@ class ReluSumPoolFn(torch.autograd.Function):
         return dx
 
 
+class MaxPool2Fn(torch.autograd.Function):
+    """F.max_pool2d(., [2, 2]) on a bf16 NHWC map (non-local block, layers.py:288-289)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        N, Hh, Ww, C = x.shape
+        x = x.contiguous()
+        out = torch.empty(N, Hh // 2, Ww // 2, C, dtype=x.dtype, device=x.device)
+        idx = torch.empty(N, Hh // 2, Ww // 2, C, dtype=torch.uint8, device=x.device)
+        H.call("ieagan_maxpool2_fwd", x.data_ptr(), out.data_ptr(), idx.data_ptr(), N, Hh, Ww, C, H.stream())
+        ctx.save_for_backward(idx)
+        ctx.shape = (N, Hh, Ww, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        N, Hh, Ww, C = ctx.shape
+        dout = dout.contiguous()
+        dx = torch.empty(N, Hh, Ww, C, dtype=dout.dtype, device=dout.device)
+        H.call("ieagan_maxpool2_bwd", dout.data_ptr(), idx.data_ptr(), dx.data_ptr(), N, Hh, Ww, C, H.stream())
+        return dx
+
+
+class GammaResidualFn(torch.autograd.Function):
+    """out = gamma * o + x on bf16 maps with the learnable scalar read from device memory (layers.py:300)."""
+
+    @staticmethod
+    def forward(ctx, o, x, gamma):
+        o, x = o.contiguous(), x.contiguous()
+        out = torch.empty_like(x)
+        H.call("ieagan_gamma_residual_fwd", o.data_ptr(), x.data_ptr(), gamma.data_ptr(), out.data_ptr(), x.numel(), H.stream())
+        ctx.save_for_backward(o, gamma)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        o, gamma = ctx.saved_tensors
+        d = d.contiguous()
+        d_o = torch.empty_like(o)
+        part = zeros((STAT_REPL,), o.device)
+        H.call("ieagan_gamma_residual_bwd", d.data_ptr(), o.data_ptr(), gamma.data_ptr(), d_o.data_ptr(), part.data_ptr(), o.numel(),
+               H.stream())
+        return d_o, d, part.sum().reshape(gamma.shape)
+
+
 # =====================================================================================================
 # augmentation
 # =====================================================================================================

@@ -126,21 +126,60 @@ class apply_ema(object):
                H.stream())
 
 
+def _ortho_plan(arena, params):
+    """Work lists of the batched ortho launch for the 2-D+ parameters ``params`` of one arena (cached per set)."""
+    key = tuple(id(p) for p in params)
+    plans = arena.__dict__.setdefault("_ortho_plans", {})
+    if key in plans:
+        return plans[key]
+    offs = {id(p): o for p, o, _ in arena.param_slices}
+    ksplit = H.lib().ieagan_ortho_ksplit()
+    tile = 64
+    table, gtiles, atiles, goff = [], [], [], 0
+    for li, p in enumerate(params):
+        R, K = p.shape[0], p.numel() // p.shape[0]
+        M, red = (R, K) if R <= K else (K, R)
+        table.append([offs[id(p)], R, K, goff])
+        goff += (M * M + 7) // 8 * 8
+        nt = (M + tile - 1) // tile
+        for ti in range(nt):
+            for tj in range(nt):
+                for sp in range((red + ksplit - 1) // ksplit):
+                    gtiles.append([li, ti, tj, sp])
+        for ti in range((R + tile - 1) // tile):
+            for tj in range((K + tile - 1) // tile):
+                atiles.append([li, ti, tj, 0])
+    dev = arena.flat.device
+    plan = dict(table=torch.tensor(table, dtype=torch.int64, device=dev), ngt=len(gtiles), nat=len(atiles),
+                gtiles=torch.tensor(gtiles, dtype=torch.int32, device=dev), atiles=torch.tensor(atiles, dtype=torch.int32, device=dev),
+                gram=torch.empty(goff, dtype=torch.float32, device=dev))
+    plans[key] = plan
+    return plan
+
+
 def ortho(model, strength=1e-4, blacklist=None):
-    """Modified orthogonal regularisation added straight to ``param.grad``:
-    2*strength * ((W W^T) (.) (1 - I)) W, evaluated as W (W^T W) - diag(|w_i|^2) W so that the Gram
-    matrix is [in, in] (256x256 for G.linear) instead of [out, out] (24576x24576 in the reference)."""
+    """Modified orthogonal regularisation added straight to ``param.grad`` (reference utils/__init__.py:843-859):
+    grad += 2*strength * ((W W^T) (.) (1 - I)) W for every parameter with >= 2 dims outside ``blacklist`` -- ONE batched
+    HIP call over the network's flat arena (csrc/ortho.hip).  Tall matrices are evaluated as
+    W (W^T W) - diag(|w_i|^2) W so the Gram matrix is [in, in] (256x256 for G.linear, not 24576x24576)."""
+    H.require_gpu()
+    from arena import arena_of
     blacklist = blacklist or []
-    with torch.no_grad():
-        for p in model.parameters():
-            if p.dim() < 2 or any(p is b for b in blacklist) or p.grad is None:
-                continue
-            w = p.view(p.shape[0], -1)
-            if w.shape[0] <= w.shape[1]:
-                g = torch.mm(torch.mm(w, w.t()).fill_diagonal_(0.0), w)
-            else:
-                g = torch.mm(w, torch.mm(w.t(), w)) - (w * w).sum(1, keepdim=True) * w
-            p.grad.add_(g.view(p.shape), alpha=2 * strength)
+    arena = arena_of(model)
+    if not arena.grads_attached():                      # stand-alone module: move its gradients into one flat buffer
+        old = [(p, p.grad) for p, _, _ in arena.param_slices]
+        arena.attach_grads()
+        with torch.no_grad():
+            for p, g in old:
+                if g is not None:
+                    p.grad.copy_(g)
+    params = [p for p in model.parameters() if p.dim() >= 2 and not any(p is b for b in blacklist) and p.grad is not None]
+    if not params:
+        return
+    plan = _ortho_plan(arena, params)
+    H.call("ieagan_ortho_grad", arena.flat.data_ptr(), arena.grad.data_ptr(), plan["table"].data_ptr(), plan["gtiles"].data_ptr(),
+           plan["ngt"], plan["atiles"].data_ptr(), plan["nat"], plan["gram"].data_ptr(), plan["gram"].numel(), float(strength),
+           H.stream())
 
 
 def count_parameters(module):

@@ -144,6 +144,15 @@ int ieagan_loss_block(const float* dfake, const float* dreal, const float* e, co
 /* D head: global sum pool of relu(h) (model.py:912) */
 int ieagan_relu_sum_pool(const void* x, float* out, int N, int HW, int C, void* stream);
 int ieagan_relu_sum_pool_bwd(const void* x, const float* dh, void* dx, int N, int HW, int C, void* stream);
+/* Non-local block glue (reference layers.py:288-300).  maxpool2: F.max_pool2d(., [2,2]) on a bf16 NHWC map [N,H,W,C]
+ * -> [N,H/2,W/2,C]; idx = one byte per output element (window position 0..3 of the first maximum).
+ * gamma_residual: out = gamma[0] * o + x (bf16, n elements, gamma a device scalar); backward d_o = gamma * d and
+ * dgamma[32 replicas, caller-zeroed] += sum(d * o); the gradient w.r.t. x is d itself. */
+int ieagan_maxpool2_fwd(const void* x, void* out, void* idx, int N, int H, int W, int C, void* stream);
+int ieagan_maxpool2_bwd(const void* dout, const void* idx, void* dx, int N, int H, int W, int C, void* stream);
+int ieagan_gamma_residual_fwd(const void* o, const void* x, const float* gamma, void* out, long n, void* stream);
+int ieagan_gamma_residual_bwd(const void* d, const void* o, const float* gamma, void* d_o, float* dgamma, long n,
+                              void* stream);
 
 /* ---- augmentation + optimiser (aug_optim.hip) -------------------------------------------------- */
 int ieagan_diffaug_fwd(const float* x, const float* bright, const float* contrast, const long* tx, const long* ty,
@@ -156,6 +165,20 @@ int ieagan_cr_diffaug(const float* x, const float* flip_u, const long* tx, const
  * derives the bias corrections on the device, so a captured HIP graph of the step stays valid. */
 int ieagan_adam_step(float* p, const float* g, float* m, float* v, long n, float* hp, void* stream);
 int ieagan_ema_update(float* tgt, const float* src, long n, const float* decay_dev, void* stream);
+
+/* ---- orthogonal regularisation (ortho.hip) -------------------------------------------------------
+ * Replaces utils.ortho (reference utils/__init__.py:843-859) for ALL weight matrices of a network in one call:
+ * grad[l] += 2*strength * ((W_l W_l^T) (.) (1 - I)) W_l, fp32, on the flat parameter / gradient arenas.
+ *   table       int64[4] per layer: {weight offset (floats) in flat == in grad, R = shape[0], K = numel / R, Gram offset}
+ *               Gram of layer l is [M,M] with M = min(R,K) (W W^T when R <= K, else W^T W), packed in `gram`
+ *   gram_tiles  int32[4] per work item: {layer, tile_i, tile_j, split} -- 64x64 Gram tiles, reduce range
+ *               [split*ieagan_ortho_ksplit(), +ieagan_ortho_ksplit()) of the long dimension
+ *   apply_tiles int32[4] per work item: {layer, tile_i (rows of W), tile_j (columns of W), 0}
+ *   gram        caller-owned scratch of gram_floats floats (zeroed by the call) */
+int ieagan_ortho_ksplit(void);
+int ieagan_ortho_grad(const float* flat, float* grad, const long* table, const int* gram_tiles, int n_gram_tiles,
+                      const int* apply_tiles, int n_apply_tiles, float* gram, long gram_floats, float strength,
+                      void* stream);
 
 /* ---- self-test of the transposed LDS read used by conv_wgrad (tests only) ---------------------- */
 int ieagan_selftest_tr_read(const void* in_bf16_64x16, void* out_bf16_64x8, void* stream);

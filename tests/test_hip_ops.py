@@ -443,3 +443,68 @@ def test_rrm_attention_core(dev, E, heads):
     (g2,) = torch.autograd.grad(out, [qkv2], go)
     close(g2, gref, 1e-4, "rrm attention grad")
     assert att.shape == (B, heads, S, S) and torch.allclose(att.sum(-1), torch.ones(B, heads, S, device=dev), atol=1e-5)
+
+
+def test_batched_ortho_vs_oracle(dev, golden_dir):
+    """utils.ortho = one batched HIP call over the arena: every >=2-D weight gets 2s((WW^T)(.)(1-I))W added to its .grad
+    (row form R<=K, column form R>K incl. a split reduce, K=9, blacklist, 1-D parameters untouched)."""
+    import ieagan_oracle as O
+    import utils
+    torch.manual_seed(5)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            mk = lambda *s: torch.nn.Parameter(torch.randn(*s) * 0.3)
+            self.conv = mk(48, 24, 3, 3)         # row form, K=216
+            self.c1 = mk(16, 1, 3, 3)            # K=9 (ragged reduce)
+            self.tall = mk(4500, 40)             # column form with 3 reduce splits
+            self.lin = mk(130, 70)               # column form, ragged tiles
+            self.emb = mk(40, 1024)
+            self.skip = mk(32, 32)               # blacklisted
+            self.vec = mk(77)                    # 1-D: not regularised
+
+    net = Net().to(dev)
+    g0 = {}
+    for n, p in net.named_parameters():
+        p.grad = torch.randn_like(p)
+        g0[n] = p.grad.clone()
+    utils.ortho(net, 1e-3, blacklist=[net.skip])
+    for n, p in net.named_parameters():
+        exp = g0[n].cpu()
+        if p.dim() >= 2 and n != "skip":
+            exp = exp + O.ortho_grad(p.detach().cpu(), 1e-3)
+        close(p.grad, exp, 2e-5, f"ortho {n}")
+    g = np.load(os.path.join(golden_dir, "op_ortho.npz"))
+    lone = torch.nn.Linear(1, 1).to(dev)
+    lone.weight = torch.nn.Parameter(torch.from_numpy(g["w"]).to(dev))
+    for p in lone.parameters():
+        p.grad = torch.zeros_like(p)
+    utils.ortho(lone, 1e-4)
+    close(lone.weight.grad, torch.from_numpy(g["g"]), 2e-5, "ortho (golden)")
+
+
+def test_nonlocal_glue_maxpool_and_gamma_residual(dev):
+    """2x2 max-pool (bf16 NHWC, first-maximum argmax like F.max_pool2d) and out = gamma*o + x with their backwards."""
+    import ops
+    torch.manual_seed(11)
+    x = (torch.randn(3, 8, 12, 16, device=dev) * 2).round().div(2).to(BF).requires_grad_(True)     # many exact ties
+    y = ops.MaxPool2Fn.apply(x)
+    xr = x.detach().float().permute(0, 3, 1, 2).requires_grad_(True)
+    yr = F.max_pool2d(xr, [2, 2])
+    assert torch.equal(y.float().permute(0, 3, 1, 2), yr), "maxpool2 forward"
+    go = torch.randn_like(yr)
+    y.backward(go.permute(0, 2, 3, 1).to(BF))
+    yr.backward(go.to(BF).float())
+    assert torch.equal(x.grad.float().permute(0, 3, 1, 2), xr.grad), "maxpool2 backward (tie-breaking)"
+
+    o = torch.randn(2, 6, 10, 24, device=dev).to(BF).requires_grad_(True)
+    xx = torch.randn(2, 6, 10, 24, device=dev).to(BF).requires_grad_(True)
+    gamma = torch.tensor(0.37, device=dev, requires_grad=True)
+    out = ops.GammaResidualFn.apply(o, xx, gamma)
+    close(out, 0.37 * o.float() + xx.float(), 8e-3, "gamma residual fwd")
+    d = torch.randn_like(out)
+    out.backward(d)
+    close(o.grad, 0.37 * d.float(), 8e-3, "gamma residual d_o")
+    assert torch.equal(xx.grad, d), "gamma residual dx"
+    close(gamma.grad, (d.float() * o.detach().float()).sum(), 1e-4, "gamma residual dgamma")
