@@ -317,7 +317,7 @@ static int launch_gather_pro(const ConvArgs& a, hipStream_t st) {
 #define HT_W 32
 
 template <bool AFF, bool RELU, int RS, int NT, int PF, int CIN>
-__global__ __launch_bounds__(256) void conv3x3_halo_kernel(ConvArgs a, int tiles_w, int tiles_h, int ntiles, int tpb, int nblk) {
+__global__ __launch_bounds__(256, (CIN >= 64 ? 2 : 1)) void conv3x3_halo_kernel(ConvArgs a, int tiles_w, int tiles_h, int ntiles, int tpb, int nblk) {
     extern __shared__ __attribute__((aligned(16))) char smem_all[];
     __shared__ float red[4 * NT * 16 * 2];
     constexpr int AW = HT_W + 2, AH = HT_H + 2;
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(ConvArgs a, int tiles
     const int H = a.H, W = a.W;
     const int Cin = (CIN > 0) ? CIN : a.Cin;              // compile-time for the prefetching variants: no runtime divisions
     const int PS = Cin * 2 + 16;                           // bytes per halo pixel
-    const int WS = a.Kpad * 2 + 16;                        // bytes per weight row in LDS (PF > 0)
+    const int WS = ((CIN > 0) ? ((9 * CIN + 31) / 32) * 32 : a.Kpad) * 2 + 16;   // bytes per weight row in LDS (PF > 0)
     const int n_base = blockIdx.y * NT * 16;
     const int chunks = Cin >> 3;
     const int total = AH * AW * chunks;
@@ -408,7 +408,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(ConvArgs a, int tiles
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) pbase[mt] = ((2 * wave + (mt >> 1)) * AW + (mt & 1) * 16 + lr) * PS;
     const int ksteps = a.Kpad >> 5;
-    const bf16* wrow = (const bf16*)a.w + (long)(col_ok ? n_base + lr : 0) * a.Kpad + lg * 8;
+    const int KP = (CIN > 0) ? ((9 * CIN + 31) / 32) * 32 : a.Kpad;     // == a.Kpad (checked by the launcher)
+    const bf16* wrow = (const bf16*)a.w + (long)(col_ok ? n_base + lr : 0) * KP + lg * 8;
 
     if (PF > 0 && t0 < t1) load_tile(t0);
     for (int t = t0; t < t1; ++t) {
@@ -416,6 +417,47 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(ConvArgs a, int tiles
         tile_coords(t, n, h0, w0);
         if (PF > 0) {
             store_tile(t);
+        } else if constexpr (CIN >= 32) {
+            // known channel count: the halo is fetched in batches of SB independent 16-byte loads per thread (all in flight
+            // together), then transformed and written to LDS -- not one load -> wait -> store round trip per chunk
+            constexpr int CH = CIN / 8, TOT = AH * AW * CH, ITERS = (TOT + 255) / 256, SB = 6;
+#pragma unroll
+            for (int b0 = 0; b0 < ITERS; b0 += SB) {
+                bf16x8 rawb[SB];
+                unsigned okb = 0;
+#pragma unroll
+                for (int j = 0; j < SB; ++j) {
+                    const int idx = threadIdx.x + (b0 + j) * 256;
+                    if (b0 + j >= ITERS || idx >= TOT) continue;
+                    const int hp = idx / CH, cc = idx - hp * CH;
+                    const int hh = h0 - 1 + hp / AW, ww = w0 - 1 + hp % AW;
+                    if (hh >= 0 && hh < H && ww >= 0 && ww < W) {
+                        const int sh_ = (RS == 1) ? (hh >> 1) : hh, sw_ = (RS == 1) ? (ww >> 1) : ww;
+                        rawb[j] = *(const bf16x8*)((const bf16*)a.src.x + (((long)n * a.src.Hs + sh_) * a.src.Ws + sw_) * a.src.Cx + cc * 8);
+                        okb |= 1u << j;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < SB; ++j) {
+                    const int idx = threadIdx.x + (b0 + j) * 256;
+                    if (b0 + j >= ITERS || idx >= TOT) continue;
+                    const int hp = idx / CH, cc = idx - hp * CH;
+                    bf16x8 o = zero8();
+                    if (okb & (1u << j)) {
+                        if (AFF || RELU) {
+                            float v[8];
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) v[i] = bf2f(rawb[j][i]);
+                            xform8<AFF, RELU>(v, a.src, n, cc * 8);
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) o[i] = f2bf(v[i]);
+                        } else {
+                            o = rawb[j];
+                        }
+                    }
+                    *(bf16x8*)(smem + hp * PS + cc * 16) = o;
+                }
+            }
         } else {
             for (int idx = threadIdx.x; idx < total; idx += 256) {
                 const int hp = idx / chunks, cc = idx - hp * chunks;
@@ -432,7 +474,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(ConvArgs a, int tiles
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int ks = 0; ks < ksteps; ++ks) {
+        auto kstep = [&](int ks) {
             const int k = ks * 32 + lg * 8;
             int tap = k / Cin;
             const int c = k - tap * Cin;
@@ -443,7 +485,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(ConvArgs a, int tiles
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 if (PF > 0) bfrag[nt] = *(const bf16x8*)(smem_all + (nt * 16 + lr) * WS + k * 2);
-                else bfrag[nt] = *(const bf16x8*)(wrow + (long)nt * 16 * a.Kpad + ks * 32);
+                else bfrag[nt] = *(const bf16x8*)(wrow + (long)nt * 16 * KP + ks * 32);
                 if (NT == 1 && !col_ok) bfrag[nt] = zero8();
             }
 #pragma unroll
@@ -454,6 +496,51 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(ConvArgs a, int tiles
                 for (int nt = 0; nt < NT; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfrag[nt], acc[mt][nt], 0, 0, 0);
             }
+        };
+        if constexpr (CIN >= 64 && PF == 0) {
+            // MFMA-bound layers: straight-line K loop with an explicit one-step-ahead software pipeline -- the weight
+            // fragments (global / L1) and the pixel fragments (LDS) of step ks+1 are requested before the 4*NT MFMAs of
+            // step ks issue; the scheduling barrier keeps the compiler from hoisting more loads (and registers) than that.
+            constexpr int KS = (9 * CIN) / 32;
+            constexpr int PSC = CIN * 2 + 16;
+            bf16x8 bq[2][NT], aq[2][4];
+            // weight address = uniform base of the n-tile (SGPR pair) + one 32-bit lane offset + immediate (ks * 64 bytes):
+            // no per-(nt, ks) pointer registers
+            const char* wnt[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wnt[nt] = (const char*)a.w + (long)(n_base + nt * 16) * (KP * 2);
+            const unsigned wlane = (unsigned)(lr * KP + lg * 8) * 2u;
+            auto ldb = [&](int ks, bf16x8(&b)[NT]) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) b[nt] = *(const bf16x8*)(wnt[nt] + wlane + (unsigned)(ks * 64));
+            };
+            auto lda = [&](int ks, bf16x8(&x)[4]) {
+                const int tap = (ks * 32) / CIN, c0 = (ks * 32) % CIN;
+                const int toff = ((tap / 3) * AW + (tap % 3)) * PSC + c0 * 2;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) x[mt] = *(const bf16x8*)(smem + pbase[mt] + lg * 16 + toff);
+            };
+            ldb(0, bq[0]);
+            lda(0, aq[0]);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks + 1 < KS) {
+                    ldb(ks + 1, bq[(ks + 1) & 1]);
+                    lda(ks + 1, aq[(ks + 1) & 1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);      // requests first, then this step's MFMAs
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[ks & 1][mt], bq[ks & 1][nt], acc[mt][nt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if constexpr (CIN >= 32) {      // channel count known at compile time (C = 16 measured faster as a rolled loop): straight-line K loop, every offset an immediate
+#pragma unroll
+            for (int ks = 0; ks < (9 * CIN + 31) / 32; ++ks) kstep(ks);
+        } else {
+            for (int ks = 0; ks < ksteps; ++ks) kstep(ks);
         }
         __syncthreads();                                   // halo consumed: its LDS becomes the epilogue buffer
         float* epi = (float*)smem + wave * EpiLds<NT>::FLOATS;
@@ -496,10 +583,20 @@ static int launch_halo_nt(const ConvArgs& a, hipStream_t st) {
     // prefetching variants: Cin = Cout = 16 / 32 (PF = ceil(340 * Cin/8 / 256) = 3 / 6)
     // small feature maps: fewer channels per block so that the grid still covers the 256 CUs
     const bool small = ntiles * ((a.Cout + 63) / 64) < 512;
-    if (a.Cin == 16 && a.Cout == 16) HALO_LAUNCH(1, 3, 16)
+    const bool kp_ok = a.Kpad == ((9 * a.Cin + 31) / 32) * 32;       // the compile-time-Cin variants assume the canonical pack
+    if (!kp_ok) {
+        if (a.Cout % 64 == 0 && !small) HALO_LAUNCH(4, 0, 0)
+        else if (a.Cout % 32 == 0 && !(small && ntiles * (a.Cout / 32) < 512)) HALO_LAUNCH(2, 0, 0)
+        else HALO_LAUNCH(1, 0, 0)
+    }
+    else if (a.Cin == 16 && a.Cout == 16) HALO_LAUNCH(1, 3, 16)
     else if (a.Cin == 32 && a.Cout == 32) HALO_LAUNCH(2, 6, 32)
     // (C = 64 with LDS-resident weights + prefetch was measured SLOWER -- 195-245 vs 270-320 TFLOP/s: one block of
     //  4 waves per CU leaves the ds_read -> MFMA latency exposed; it needs a hand-pipelined K loop first.)
+    else if (a.Cin == 64 && a.Cout % 64 == 0 && !small) HALO_LAUNCH(4, 0, 64)
+    else if (a.Cin == 128 && a.Cout % 64 == 0 && !small) HALO_LAUNCH(4, 0, 128)
+    else if (a.Cin == 128 && a.Cout % 32 == 0 && !(small && ntiles * (a.Cout / 32) < 512)) HALO_LAUNCH(2, 0, 128)
+    else if (a.Cin == 64 && a.Cout % 32 == 0 && !(small && ntiles * (a.Cout / 32) < 512)) HALO_LAUNCH(2, 0, 64)
     else if (a.Cout % 64 == 0 && !small) HALO_LAUNCH(4, 0, 0)
     else if (a.Cout % 32 == 0 && !(small && ntiles * (a.Cout / 32) < 512)) HALO_LAUNCH(2, 0, 0)
     else HALO_LAUNCH(1, 0, 0)
@@ -533,7 +630,11 @@ int conv_gather_launch(const ConvArgs& a, hipStream_t st) {
     if (a.ra && a.ra_rs == 1) CHECK_ARG(a.H % 2 == 0 && a.W % 2 == 0, "conv: upsampled residual needs even H, W");
     if (a.rb) CHECK_ARG(a.Crb % 8 == 0 && a.Crb >= a.Cout - a.Ca, "conv: bad residual-B channel count");
     const double flops = 2.0 * a.N * a.H * a.W * (double)a.Cout * a.taps * a.Cin;
-    const double bytes = 2.0 * a.N * ((double)a.src.Hs * a.src.Ws * a.Cin + (double)a.H * a.W * a.Cout);
+    // algorithmic bytes: source + output + the epilogue operands (ReLU mask, residual slices at their own resolution)
+    double bytes = 2.0 * a.N * ((double)a.src.Hs * a.src.Ws * a.Cin + (double)a.H * a.W * a.Cout);
+    if (a.mask) bytes += 2.0 * a.N * (double)a.H * a.W * a.Cout;
+    if (a.ra) bytes += 2.0 * a.N * (double)a.H * a.W * a.Ca * (a.ra_rs == 1 ? 0.25 : (a.ra_rs == 2 ? 4.0 : 1.0));
+    if (a.rb) bytes += 2.0 * a.N * (double)a.H * a.W * (a.Cout - a.Ca);
     const bool halo = a.taps == 9 && a.src.rs != 2 && a.W >= 16 && a.H >= 4 && a.Cin % 16 == 0 && !g_force_gather &&
                       (size_t)(HT_H + 2) * (HT_W + 2) * (a.Cin * 2 + 16) <= 150 * 1024;
     char tag[64] = "";
