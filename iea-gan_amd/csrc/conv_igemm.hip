@@ -811,8 +811,11 @@ int conv_wgrad_launch(const WgradArgs& a0, hipStream_t st, int use_tr) {
     const int nt_total = a.taps * (a.Cin / 16);
     const int gy = (nt_total + 15) / 16;
     const long tiles = (long)a.N * ((a.H + WG_TH - 1) / WG_TH) * ((a.W + WG_TW - 1) / WG_TW);
-    // split-K over ~1024 blocks in x (each block atomically adds its partial sums once)
-    long target = 1024 / (gy * gz);
+    // Every block ends with one float atomicAdd per owned dW element, and the chip retires only ~1.3 TB/s of atomics:
+    // the larger dW is, the fewer pixel splits pay off (measured optimum per layer size on MI355X).
+    const long dw_elems = (long)a.Cout * a.taps * a.Cin;
+    const long blocks_goal = dw_elems <= 4096 ? 2048 : dw_elems <= 12288 ? 1024 : (dw_elems <= 65536 || tiles > 128) ? 512 : 256;
+    long target = blocks_goal / (gy * gz);
     if (target < 64) target = 64;
     int tpb = (int)((tiles + target - 1) / target);
     if (tpb < 1) tpb = 1;

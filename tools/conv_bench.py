@@ -1,0 +1,41 @@
+"""Micro-benchmark of one fused-conv launch (development aid): python tools/conv_bench.py N H W Cin Cout taps [relu] [mask] [iters]"""
+import os, sys
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(root, "iea-gan_amd"), root]
+import torch
+import _hip as H
+import ops
+
+N, Hh, Ww, Cin, Cout, taps = map(int, sys.argv[1:7])
+relu = int(sys.argv[7]) if len(sys.argv) > 7 else 0
+mask = int(sys.argv[8]) if len(sys.argv) > 8 else 0
+iters = int(sys.argv[9]) if len(sys.argv) > 9 else 20
+H.require_gpu()
+dev = "cuda:0"
+x = torch.randn(N, Hh, Ww, Cin, device=dev).to(torch.bfloat16)
+kpad = ops._kpad(taps * Cin)
+w = (torch.randn(Cout, kpad, device=dev) * 0.05).to(torch.bfloat16)
+bias = torch.randn(Cout, device=dev)
+out = torch.empty(N, Hh, Ww, Cout, device=dev, dtype=torch.bfloat16)
+mk = torch.randn(N, Hh, Ww, Cout, device=dev).to(torch.bfloat16) if mask else None
+stats = torch.zeros(32, 2, Cout, device=dev)
+
+
+def run():
+    ops._conv_launch(x, Cin, Hh, Ww, 0, None, None, 0, bool(relu), N, Hh, Ww, Cin, Cout, taps, kpad, w, bias, None, 0, 0, 0, None, 0, mk, out,
+                     stats)
+
+
+for _ in range(3):
+    run()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(iters):
+    run()
+e1.record()
+torch.cuda.synchronize()
+us = e0.elapsed_time(e1) * 1e3 / iters
+flops = 2.0 * N * Hh * Ww * Cout * taps * Cin
+byts = 2.0 * N * Hh * Ww * (Cin + Cout * (2 if mask else 1))
+print(f"conv {taps}tap N{N} {Hh}x{Ww} {Cin}->{Cout} relu{relu} mask{mask}: {us:.1f} us  {flops/us/1e6:.0f} TF  {byts/us/1e3:.0f} GB/s")
