@@ -62,6 +62,7 @@ _SIGS = {
     "ieagan_conv_1toC": [vp, vp, vp, vp, vp, i, i, i, i, i, vp],
     "ieagan_conv_Cto1": [vp, vp, vp, i, i, vp, vp, vp, i, i, i, i, i, i, vp],
     "ieagan_wgrad_c1": [vp, vp, vp, vp, vp, i, i, vp, i, i, i, i, i, vp],
+    "ieagan_sn_backward_batched": [vp, vp, i, vp, vp, vp, vp, vp],
     "ieagan_sn_forward": [vp, vp, i, vp, i, vp, vp, vp, vp, f, i, vp],
     "ieagan_sn_backward": [vp, vp, i, i, i, i, i, i, vp, vp, vp, i, vp, vp, i, vp],
     "ieagan_sn_backward_stack": [vp, vp, vp, vp, i, vp, vp, vp, vp, i, vp],

@@ -280,6 +280,79 @@ extern "C" int ieagan_sn_backward(const float* gsn, const float* W, int kind, in
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Every conv layer of a network in two launches, at the end of a backward pass.  The wgrad kernels of the pass have
+// accumulated their gradients w.r.t. the normalised weights (and the replicated bias column sums) into ONE scratch
+// arena; this maps them through d(W/sigma)/dW and adds the result to the flat gradient arena.
+//   btab  int64[12] per layer: {weight offset (params == grad arena), out, in, taps, cin, kind, kpad, ctx offset,
+//                               gsn offset in scratch, colsum offset in scratch or -1, bias offset in grad or -1, bias length}
+//   work  int32[2] per block: {layer, chunk of SNB_CHUNK elements};  scratch[0 .. nlayers) = <gsn, W> accumulators (zeroed)
+// ------------------------------------------------------------------------------------------------
+#define SNB_FIELDS 12
+#define SNB_CHUNK 2048
+
+__global__ __launch_bounds__(256) void sn_bwd_batch_inner_kernel(const long* __restrict__ btab, const int* __restrict__ work,
+                                                                 const float* __restrict__ params, float* __restrict__ scratch) {
+    __shared__ float red[4];
+    const int layer = work[2 * blockIdx.x], chunk = work[2 * blockIdx.x + 1];
+    const long* L = btab + (long)layer * SNB_FIELDS;
+    const float* W = params + L[0];
+    const int out = (int)L[1], in = (int)L[2], taps = (int)L[3], cin = (int)L[4], kind = (int)L[5], kpad = (int)L[6];
+    const float* gsn = scratch + L[8];
+    const long total = (long)out * in;
+    const long e1 = min(total, (long)(chunk + 1) * SNB_CHUNK);
+    float s = 0.f;
+    for (long e = (long)chunk * SNB_CHUNK + threadIdx.x; e < e1; e += 256) {
+        const int o = (int)(e / in), i = (int)(e % in);
+        s += gsn_at(gsn, kind, o, i, out, in, taps, cin, kpad) * W[e];
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) atomicAdd(scratch + layer, s);
+}
+
+__global__ __launch_bounds__(256) void sn_bwd_batch_apply_kernel(const long* __restrict__ btab, const int* __restrict__ work,
+                                                                 const float* __restrict__ ctx_all, const float* __restrict__ scratch,
+                                                                 float* __restrict__ grad) {
+    const int layer = work[2 * blockIdx.x], chunk = work[2 * blockIdx.x + 1];
+    const long* L = btab + (long)layer * SNB_FIELDS;
+    const int out = (int)L[1], in = (int)L[2], taps = (int)L[3], cin = (int)L[4], kind = (int)L[5], kpad = (int)L[6];
+    const float* ctx = ctx_all + L[7];
+    const float* gsn = scratch + L[8];
+    float* dW = grad + L[0];
+    const float isg = 1.f / ctx[0];
+    const float coef = scratch[layer] * isg * isg;
+    const float* u = ctx + 8;
+    const float* v = ctx + 8 + out + in;
+    const long total = (long)out * in;
+    const long e1 = min(total, (long)(chunk + 1) * SNB_CHUNK);
+    for (long e = (long)chunk * SNB_CHUNK + threadIdx.x; e < e1; e += 256) {
+        const int o = (int)(e / in), i = (int)(e % in);
+        dW[e] += gsn_at(gsn, kind, o, i, out, in, taps, cin, kpad) * isg - coef * u[o] * v[i];
+    }
+    if (chunk == 0 && L[9] >= 0) {
+        const float* colsum = scratch + L[9];
+        float* dbias = grad + L[10];
+        const int nb = (int)L[11];
+        for (int c = threadIdx.x; c < nb; c += 256) {
+            float b = 0.f;
+            for (int r = 0; r < STAT_REPL; ++r) b += colsum[r * nb + c];
+            dbias[c] += b;
+        }
+    }
+}
+
+extern "C" int ieagan_sn_backward_batched(const long* btab, const int* work, int nwork, const float* params, const float* ctx,
+                                          float* scratch, float* grad, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (nwork <= 0) return 0;
+    CHECK_ARG(btab && work && params && ctx && scratch && grad, "sn_backward_batched: null pointer");
+    ProfScope prof("sn_backward_batched", 0.0, 0.0, st);
+    hipLaunchKernelGGL(sn_bwd_batch_inner_kernel, dim3(nwork), dim3(256), 0, st, btab, work, params, scratch);
+    hipLaunchKernelGGL(sn_bwd_batch_apply_kernel, dim3(nwork), dim3(256), 0, st, btab, work, ctx, (const float*)scratch, grad);
+    CHECK_LAUNCH("sn_backward_batched");
+    return 0;
+}
+
 // every ccbn gain / bias SNLinear of a generator at once: block b handles stack layer b.
 //   gst [sum out][in] gradient w.r.t. the stacked normalised rows; layers[b] = table row of layer b;
 //   dst[b] = element offset of that layer's weight gradient inside grad_base

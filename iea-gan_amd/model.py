@@ -78,6 +78,11 @@ def _sn_children(module, prefix):
     return out
 
 
+def _sn_biases(module):
+    """name -> bias parameter of every spectrally normalised conv below ``module`` (batched SN backward)."""
+    return {n: m.bias for n, m in _sn_children(module, "") if isinstance(m, layers.SNConv2d) and getattr(m, "bias", None) is not None}
+
+
 # =====================================================================================================
 # generator
 # =====================================================================================================
@@ -212,7 +217,7 @@ class Generator(nn.Module):
                 cmap[bn_name] = (c0, c0 + b.output_size)
                 c0 += 2 * b.output_size
             cols.append(cmap)
-        bank = ops.SNBank(ar.flat, entries, stack=stack)
+        bank = ops.SNBank(ar.flat, entries, stack=stack, owner=ar, biases=_sn_biases(self))
         modmap = dict(_sn_children(self, ""))
         sw = [modmap[n].weight for n in stack]
         offs = {id(p): o for p, o, _ in ar.param_slices}
@@ -363,7 +368,7 @@ class Discriminator(nn.Module):
         if self._plan is not None and self._plan["arena"] is ar:
             return self._plan
         entries = [(n, m._sn_kind, m.weight, m.u0, m.sv0) for n, m in _sn_children(self, "")]
-        self._plan = dict(arena=ar, bank=ops.SNBank(ar.flat, entries))
+        self._plan = dict(arena=ar, bank=ops.SNBank(ar.flat, entries, owner=ar, biases=_sn_biases(self)))
         return self._plan
 
     def forward(self, x, y=None):

@@ -98,7 +98,62 @@ KIND_PLAIN, KIND_CONV, KIND_C1_IN, KIND_C1_OUT = 0, 1, 2, 3
 
 class SNRecord:
     """What one forward pass knows about one spectrally normalised layer."""
-    __slots__ = ("kind", "out", "inn", "taps", "cin", "kpad", "kpad2", "w_fwd", "w_bwd", "w_plain", "ctx")
+    __slots__ = ("kind", "out", "inn", "taps", "cin", "kpad", "kpad2", "w_fwd", "w_bwd", "w_plain", "ctx", "name", "pass_",
+                 "deferred")
+
+
+class SNPass:
+    """One forward pass of a network through its SN bank.  In training (gradients accumulated straight into the flat
+    gradient arena) the conv layers' weight-gradient kernels of the matching backward pass write into ONE zeroed scratch
+    arena owned by this object, and a single batched launch at the end of ``backward()`` maps all of them through
+    d(W/sigma)/dW -- instead of one small launch chain per layer."""
+
+    def __init__(self, bank, ctx):
+        self.bank, self.ctx, self.arena, self._ok = bank, ctx, None, None
+
+    def usable(self) -> bool:
+        if not DIRECT_GRADS or self.bank.owner is None or self.bank.bwd is None:
+            return False
+        if self._ok is None:
+            self._ok = self.bank.owner.grads_attached()
+        return self._ok
+
+    def scratch(self, name, which, shape):
+        """View of this pass's scratch arena for layer ``name`` ('w': weight gradient, 'b': bias column sums) or None."""
+        if not self.usable() or name not in self.bank.bwd["rows"]:
+            return None
+        goff, coff = self.bank.bwd["rows"][name]
+        off = goff if which == "w" else coff
+        if off < 0:
+            return None
+        if self.arena is None:
+            self.arena = zeros((self.bank.bwd["total"],), self.ctx.device)
+            from torch.autograd import Variable
+            Variable._execution_engine.queue_callback(self.flush)
+        n = 1
+        for d in shape:
+            n *= int(d)
+        return self.arena[off:off + n].view(shape)
+
+    def flush(self):
+        if self.arena is None:
+            return
+        b = self.bank
+        H.call("ieagan_sn_backward_batched", b.bwd["table"].data_ptr(), b.bwd["work"].data_ptr(), b.bwd["nwork"], b.arena.data_ptr(),
+               self.ctx.data_ptr(), self.arena.data_ptr(), b.owner.grad.data_ptr(), H.stream())
+        self.arena = None
+
+
+def sn_scratch(rec, which, shape, device):
+    """Zeroed fp32 accumulator for a layer's weight gradient / bias column sums: a slice of the pass's batched-backward
+    arena when that path is active (then ``sn_backward`` is a no-op for the layer), else a private pool buffer."""
+    ps = getattr(rec, "pass_", None)
+    if ps is not None:
+        v = ps.scratch(rec.name, which, shape)
+        if v is not None:
+            rec.deferred = True
+            return v
+    return zeros(shape, device)
 
 
 class SNBank:
@@ -110,8 +165,9 @@ class SNBank:
 
     ROWS = 32
 
-    def __init__(self, arena: torch.Tensor, entries, stack=()):
+    def __init__(self, arena: torch.Tensor, entries, stack=(), owner=None, biases=None):
         self.arena = arena
+        self.owner, self.bwd = owner, None          # owner: the network's Arena (flat gradient buffer) -> batched backward
         self.names = [e[0] for e in entries]
         self.index = {n: i for i, n in enumerate(self.names)}
         dev = arena.device
@@ -170,6 +226,35 @@ class SNBank:
         self.blocks = torch.tensor(blocks, dtype=torch.int32, device=dev)
         self.cblocks = torch.tensor(cblocks, dtype=torch.int32, device=dev)
         self.nblocks, self.ncblocks = len(blocks), len(cblocks)
+        if owner is not None:
+            self._plan_backward(entries, biases or {})
+
+    def _plan_backward(self, entries, biases):
+        """Static layout of the per-pass scratch arena and the work list of ``ieagan_sn_backward_batched``."""
+        offs = {id(p): o for p, o, _ in self.owner.param_slices}
+        al = lambda n: (n + 63) // 64 * 64
+        conv = [(i, e) for i, e in enumerate(entries) if e[1] != KIND_PLAIN]
+        if not conv:
+            return
+        goff = al(len(conv))                         # [0, n_layers): the <gsn, W> accumulators
+        rows, tab, work = {}, [], []
+        for li, (i, (n, kind, w, u, sv)) in enumerate(conv):
+            _, out, inn, taps, cin, kpad, _, coff, _, _ = self.meta[i]
+            gsz = out * kpad if kind == KIND_CONV else out * inn
+            b = biases.get(n)
+            nb = 0 if (b is None or kind == KIND_C1_OUT) else out
+            tab.append([offs[id(w)], out, inn, taps, cin, kind, kpad, coff, goff, -1, offs[id(b)] if nb else -1, nb])
+            rows[n] = [goff, -1]
+            goff += al(gsz)
+            for c in range((out * inn + 2047) // 2048):
+                work.append([li, c])
+        for li, (i, (n, kind, w, u, sv)) in enumerate(conv):
+            if tab[li][11]:
+                tab[li][9] = rows[n][1] = goff
+                goff += al(STAT_REPL * tab[li][11])
+        dev = self.arena.device
+        self.bwd = dict(rows={k: tuple(v) for k, v in rows.items()}, total=goff, nwork=len(work),
+                        table=torch.tensor(tab, dtype=torch.int64, device=dev), work=torch.tensor(work, dtype=torch.int32, device=dev))
 
     def run(self, training: bool, eps: float):
         dev = self.arena.device
@@ -180,9 +265,11 @@ class SNBank:
                self.ncblocks, self.arena.data_ptr(), ctx.data_ptr(), part.data_ptr(), pack.data_ptr(), float(eps),
                int(training), H.stream())
         recs = {}
+        ps = SNPass(self, ctx)
         for n, (kind, out, inn, taps, cin, kpad, kpad2, coff, p1, p2) in zip(self.names, self.meta):
             r = SNRecord()
             r.kind, r.out, r.inn, r.taps, r.cin, r.kpad, r.kpad2 = kind, out, inn, taps, cin, kpad, kpad2
+            r.name, r.pass_, r.deferred = n, ps, False
             r.ctx = ctx[coff:coff + 8 + 2 * out + 2 * inn]
             r.w_fwd = r.w_bwd = r.w_plain = None
             if kind == KIND_CONV:
@@ -210,6 +297,8 @@ def sn_backward(gsn: torch.Tensor, weight: torch.Tensor, rec: SNRecord, colsum=N
     """Gradient of the parameter ``weight`` from the gradient w.r.t. its normalised form (consumer layout),
     plus (optionally) the bias gradient folded from replicated column sums.  Returns (dW, dbias); an entry is
     None when it was accumulated directly into ``param.grad`` (see DIRECT_GRADS)."""
+    if getattr(rec, "deferred", False):          # gsn / colsum live in the pass arena: handled by SNPass.flush
+        return None, None
     tgt = _direct_target(weight)
     dW = tgt if tgt is not None else torch.empty_like(weight)
     btgt = _direct_target(bias) if colsum is not None else None
@@ -433,12 +522,14 @@ class ConvFn(torch.autograd.Function):
         dbias = None
         if dstats is not None:
             geff = torch.empty_like(g)
-            colsum = zeros((STAT_REPL, Cout), dev) if has_bias else None
+            colsum = None
+            if has_bias:
+                colsum = sn_scratch(rec, "b", (STAT_REPL, Cout), dev) if (need[1] and need[2]) else zeros((STAT_REPL, Cout), dev)
             H.call("ieagan_effgrad", g.data_ptr(), out.data_ptr(), dstats[0].contiguous().data_ptr(), geff.data_ptr(),
                    H.ptr(colsum), P, Cout, H.stream())
             g = geff
         elif has_bias and need[2]:
-            colsum = zeros((STAT_REPL, Cout), dev)
+            colsum = sn_scratch(rec, "b", (STAT_REPL, Cout), dev) if need[1] else zeros((STAT_REPL, Cout), dev)
             H.call("ieagan_effgrad", g.data_ptr(), None, None, None, colsum.data_ptr(), P, Cout, H.stream())
         # ---- residual operands
         d_ra = d_rb = None
@@ -504,7 +595,7 @@ class ConvFn(torch.autograd.Function):
         # ---- weight gradient (skipped entirely when the parameter is frozen, e.g. D in the G phase)
         dW = None
         if need[1]:
-            dwp = zeros((Cout, rec.kpad), dev)
+            dwp = sn_scratch(rec, "w", (Cout, rec.kpad), dev)
             d = H.WgradDesc(N, Hc, Wc, Cin, Cout, taps, rec.kpad,
                             H.src_desc(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu), g.data_ptr(), Cout, dwp.data_ptr(), 0)
             H.call("ieagan_conv_wgrad", d, int(USE_TR_READ), H.stream())
@@ -548,14 +639,14 @@ class InputConvFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         dimg = dW = dbias = colsum = None
         if need[2]:
-            colsum = zeros((STAT_REPL, C), dev)
+            colsum = sn_scratch(rec, "b", (STAT_REPL, C), dev) if need[1] else zeros((STAT_REPL, C), dev)
             H.call("ieagan_effgrad", g.data_ptr(), None, None, None, colsum.data_ptr(), N * Hh * Ww, C, H.stream())
         if need[0]:
             dimg = torch.empty(N, 1, Hh, Ww, dtype=torch.float32, device=dev)
             H.call("ieagan_conv_Cto1", g.data_ptr(), None, None, 0, 0, rec.w_plain.data_ptr(), None, dimg.data_ptr(), 0, N, Hh,
                    Ww, C, 1, H.stream())
         if need[1]:
-            dw = zeros((9, C), dev)
+            dw = sn_scratch(rec, "w", (9, C), dev)
             H.call("ieagan_wgrad_c1", img.data_ptr(), None, g.data_ptr(), None, None, 0, 0, dw.data_ptr(), N, Hh, Ww, C, 0,
                    H.stream())
             dW, dbias = sn_backward(dw, weight, rec, colsum, ctx.bias_ref)
@@ -597,7 +688,7 @@ class OutputConvFn(torch.autograd.Function):
             H.call("ieagan_prologue_bwd", da.data_ptr(), h.data_ptr(), C, scale.data_ptr(), shift.data_ptr(), 0, 1, 0,
                    dh.data_ptr(), dscale.data_ptr(), dshift.data_ptr(), N, Hh, Ww, C, None, 0, 0, 0, H.stream())
         if need[3]:
-            dw = zeros((9, C), dev)
+            dw = sn_scratch(rec, "w", (9, C), dev)
             H.call("ieagan_wgrad_c1", dpre.data_ptr(), None, h.data_ptr(), scale.data_ptr(), shift.data_ptr(), 0, 1, dw.data_ptr(),
                    N, Hh, Ww, C, 1, H.stream())
             dW = sn_backward(dw, weight, rec)[0]

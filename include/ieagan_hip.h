@@ -121,6 +121,14 @@ int ieagan_sn_backward(const float* gsn, const float* W, int kind, int out, int 
 int ieagan_sn_backward_stack(const long* table, const int* layers, const long* row0, const long* dst, int nlayers,
                              const float* gst, const float* params, const float* ctx, float* grad_base, int accumulate,
                              void* stream);
+/* All conv layers of a network at the end of one backward pass (two launches).  The pass's wgrad kernels accumulated
+ * d/d(W/sigma) (consumer layout) and the replicated bias column sums into ONE caller-zeroed scratch arena:
+ *   btab  int64[12] per layer: {weight offset (same in params and grad), out, in, taps, cin, kind, kpad, ctx offset,
+ *                               gsn offset in scratch, colsum offset in scratch or -1, bias offset in grad or -1, bias length}
+ *   work  int32[2] per block : {layer, chunk of 2048 weight elements};  scratch[0 .. nlayers) = <gsn, W> accumulators
+ * grad (the flat gradient arena) is accumulated into. */
+int ieagan_sn_backward_batched(const long* btab, const int* work, int nwork, const float* params, const float* ctx,
+                               float* scratch, float* grad, void* stream);
 
 /* ---- non-local self-attention core (attention.hip): softmax(theta^T phi) applied to g, layers.py:291-299,
  * streaming softmax (no [N, Lq, Lk] tensor).  Q [N,Lq,dqk], K [N,Lk,dqk], V [N,Lk,dv], O [N,Lq,dv] bf16;
