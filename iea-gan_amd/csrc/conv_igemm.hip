@@ -21,11 +21,28 @@
 // conv-input pixel (n, hh, ww) at conv resolution; zero outside the image (conv padding is applied
 // AFTER the activation, as in the reference where the activated tensor is what gets padded).
 // ------------------------------------------------------------------------------------------------
+// Per-(n, c) scale / shift of the fused BatchNorm apply.  `aff` (optional) is a block-resident LDS copy of image n's rows,
+// [0, AFF_MAXC) scale and [AFF_MAXC, 2*AFF_MAXC) shift: the table is 64 bytes per 16 bytes of activation when fetched
+// through the vector-memory path, which made the affine variants address-unit bound.
+#define AFF_MAXC 512
+__device__ __forceinline__ void stage_aff(float* aff, const SrcDesc& s, int n, int Cin) {
+    for (int i = threadIdx.x; i < Cin; i += 256) {
+        aff[i] = s.scale[(long)n * s.aff_nstride + i];
+        aff[AFF_MAXC + i] = s.shift[(long)n * s.aff_nstride + i];
+    }
+}
+
 template <bool AFF, bool RELU>
-__device__ __forceinline__ void xform8(float (&v)[8], const SrcDesc& s, int n, int c) {
+__device__ __forceinline__ void xform8(float (&v)[8], const SrcDesc& s, int n, int c, const float* aff = nullptr) {
     if (AFF) {
-        const f32x8 sc = *(const f32x8*)(s.scale + (long)n * s.aff_nstride + c);
-        const f32x8 sh = *(const f32x8*)(s.shift + (long)n * s.aff_nstride + c);
+        f32x8 sc, sh;
+        if (aff != nullptr) {
+            sc = *(const f32x8*)(aff + c);
+            sh = *(const f32x8*)(aff + AFF_MAXC + c);
+        } else {
+            sc = *(const f32x8*)(s.scale + (long)n * s.aff_nstride + c);
+            sh = *(const f32x8*)(s.shift + (long)n * s.aff_nstride + c);
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = v[i] * sc[i] + sh[i];
     }
@@ -36,7 +53,8 @@ __device__ __forceinline__ void xform8(float (&v)[8], const SrcDesc& s, int n, i
 }
 
 template <bool AFF, bool RELU, int RS>
-__device__ __forceinline__ bf16x8 gather8(const SrcDesc& s, int H, int W, int n, int hh, int ww, int c, bool ok) {
+__device__ __forceinline__ bf16x8 gather8(const SrcDesc& s, int H, int W, int n, int hh, int ww, int c, bool ok,
+                                          const float* aff = nullptr) {
     ok = ok && (hh >= 0) && (hh < H) && (ww >= 0) && (ww < W);
     if (!ok) return zero8();
     if (RS == 2) {  // conv pixel = mean of the 2x2 source block (AvgPool2d(2) of the activated source)
@@ -49,7 +67,7 @@ __device__ __forceinline__ bf16x8 gather8(const SrcDesc& s, int H, int W, int n,
             float v[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = bf2f(raw[i]);
-            xform8<AFF, RELU>(v, s, n, c);
+            xform8<AFF, RELU>(v, s, n, c, aff);
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] += v[i];
         }
@@ -64,7 +82,7 @@ __device__ __forceinline__ bf16x8 gather8(const SrcDesc& s, int H, int W, int n,
     float v[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = bf2f(raw[i]);
-    xform8<AFF, RELU>(v, s, n, c);
+    xform8<AFF, RELU>(v, s, n, c, aff);
     bf16x8 o;
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = f2bf(v[i]);
@@ -199,10 +217,11 @@ __device__ __forceinline__ void stats_flush(const ConvArgs& a, float (&s1)[8], f
 // conv_gather: block = 4 waves, each wave 2 m-tiles (32 pixels) x NT n-tiles (16*NT channels);
 // A fragments gathered straight from global memory (any H, W; 1x1 and small 3x3 layers).
 // ------------------------------------------------------------------------------------------------
-template <int TAPS, bool AFF, bool RELU, int RS, int NT>
+template <int TAPS, bool AFF, bool RELU, int RS, int NT, bool LAFF>
 __global__ __launch_bounds__(256) void conv_gather_kernel(ConvArgs a) {
     __shared__ __attribute__((aligned(16))) float epi[4 * EpiLds<NT>::FLOATS];
     __shared__ float red[4 * NT * 16 * 2];
+    __shared__ __attribute__((aligned(32))) float aff_s[LAFF ? 2 * AFF_MAXC : 8];   // LAFF: all 128 pixels of a block share one image
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 15, lg = lane >> 4;
     const int H = a.H, W = a.W, HW = H * W;
@@ -228,6 +247,10 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(ConvArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    if (LAFF) {
+        stage_aff(aff_s, a.src, (int)(((long)blockIdx.x * 128) / HW), a.Cin);
+        __syncthreads();
+    }
     const int ksteps = a.Kpad >> 5;
     const bool col_ok = (n_base + (NT - 1) * 16 + lr) < a.Cout;     // only NT == 1 can have a half-empty n-tile
     const bf16* wrow = (const bf16*)a.w + (long)(col_ok ? n_base + lr : 0) * a.Kpad + lg * 8;
@@ -249,7 +272,8 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(ConvArgs a) {
         }
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            const bf16x8 af = gather8<AFF, RELU, RS>(a.src, H, W, pn[mt], ph[mt] + dy, pw[mt] + dx, c, pv[mt] && kval);
+            const bf16x8 af = gather8<AFF, RELU, RS>(a.src, H, W, pn[mt], ph[mt] + dy, pw[mt] + dx, c, pv[mt] && kval,
+                                                     LAFF ? aff_s : nullptr);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfrag[nt], acc[mt][nt], 0, 0, 0);
@@ -281,13 +305,17 @@ static int launch_gather_nt(const ConvArgs& a, hipStream_t st) {
     const unsigned gx = (unsigned)((M + 127) / 128);
     // tiny feature maps (4x12 ... 16x48): split the output channels over more blocks to cover the chip
     const bool small4 = (long)gx * (a.Cout / 64) < 512, small2 = (long)gx * (a.Cout / 32) < 512;
-    if (a.Cout % 64 == 0 && !small4) {
-        hipLaunchKernelGGL((conv_gather_kernel<TAPS, AFF, RELU, RS, 4>), dim3(gx, a.Cout / 64), dim3(256), 0, st, a);
-    } else if (a.Cout % 32 == 0 && !(small4 && small2 && a.Cout % 64 == 0)) {
-        hipLaunchKernelGGL((conv_gather_kernel<TAPS, AFF, RELU, RS, 2>), dim3(gx, a.Cout / 32), dim3(256), 0, st, a);
-    } else {
-        hipLaunchKernelGGL((conv_gather_kernel<TAPS, AFF, RELU, RS, 1>), dim3(gx, (a.Cout + 15) / 16), dim3(256), 0, st, a);
+    // affine table in LDS when every 128-pixel block lies inside one image (all but the tiniest maps)
+    const bool laff = AFF && ((long)a.H * a.W) % 128 == 0 && a.Cin <= AFF_MAXC;
+#define GATHER_LAUNCH(NTV, GY)                                                                                                  \
+    {                                                                                                                           \
+        if (AFF && laff) hipLaunchKernelGGL((conv_gather_kernel<TAPS, AFF, RELU, RS, NTV, AFF>), dim3(gx, GY), dim3(256), 0, st, a); \
+        else hipLaunchKernelGGL((conv_gather_kernel<TAPS, AFF, RELU, RS, NTV, false>), dim3(gx, GY), dim3(256), 0, st, a);      \
     }
+    if (a.Cout % 64 == 0 && !small4) GATHER_LAUNCH(4, a.Cout / 64)
+    else if (a.Cout % 32 == 0 && !(small4 && small2 && a.Cout % 64 == 0)) GATHER_LAUNCH(2, a.Cout / 32)
+    else GATHER_LAUNCH(1, (a.Cout + 15) / 16)
+#undef GATHER_LAUNCH
     return 0;
 }
 
@@ -351,6 +379,9 @@ __global__ __launch_bounds__(256, (CIN >= 64 ? 2 : 1)) void conv3x3_halo_kernel(
             *(bf16x8*)(smem_all + row * WS + kc * 16) = v;
         }
     }
+    __shared__ __attribute__((aligned(32))) float aff_s[AFF ? 2 * AFF_MAXC : 8];
+    const float* affp = AFF ? aff_s : nullptr;             // Cin <= AFF_MAXC is checked by the launcher
+    int aff_n = -1;
     bf16x8 raw[PF > 0 ? PF : 1];
     unsigned okmask = 0;
     auto tile_coords = [&](int t, int& n, int& h0, int& w0) {
@@ -390,7 +421,7 @@ __global__ __launch_bounds__(256, (CIN >= 64 ? 2 : 1)) void conv3x3_halo_kernel(
                     float v[8];
 #pragma unroll
                     for (int i = 0; i < 8; ++i) v[i] = bf2f(raw[j][i]);
-                    xform8<AFF, RELU>(v, a.src, n, cc * 8);
+                    xform8<AFF, RELU>(v, a.src, n, cc * 8, affp);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) o[i] = f2bf(v[i]);
                 } else {
@@ -415,6 +446,12 @@ __global__ __launch_bounds__(256, (CIN >= 64 ? 2 : 1)) void conv3x3_halo_kernel(
     for (int t = t0; t < t1; ++t) {
         int n, h0, w0;
         tile_coords(t, n, h0, w0);
+        if (AFF && n != aff_n) {        // block-uniform: (re)load this image's scale / shift rows
+            __syncthreads();
+            stage_aff(aff_s, a.src, n, Cin);
+            aff_n = n;
+            __syncthreads();
+        }
         if (PF > 0) {
             store_tile(t);
         } else if constexpr (CIN >= 32) {
@@ -448,7 +485,7 @@ __global__ __launch_bounds__(256, (CIN >= 64 ? 2 : 1)) void conv3x3_halo_kernel(
                             float v[8];
 #pragma unroll
                             for (int i = 0; i < 8; ++i) v[i] = bf2f(rawb[j][i]);
-                            xform8<AFF, RELU>(v, a.src, n, cc * 8);
+                            xform8<AFF, RELU>(v, a.src, n, cc * 8, affp);
 #pragma unroll
                             for (int i = 0; i < 8; ++i) o[i] = f2bf(v[i]);
                         } else {
@@ -462,7 +499,7 @@ __global__ __launch_bounds__(256, (CIN >= 64 ? 2 : 1)) void conv3x3_halo_kernel(
             for (int idx = threadIdx.x; idx < total; idx += 256) {
                 const int hp = idx / chunks, cc = idx - hp * chunks;
                 const int hh = h0 - 1 + hp / AW, ww = w0 - 1 + hp % AW;
-                const bf16x8 v = gather8<AFF, RELU, RS>(a.src, H, W, n, hh, ww, cc * 8, true);
+                const bf16x8 v = gather8<AFF, RELU, RS>(a.src, H, W, n, hh, ww, cc * 8, true, affp);
                 *(bf16x8*)(smem + hp * PS + cc * 16) = v;
             }
         }
@@ -636,7 +673,7 @@ int conv_gather_launch(const ConvArgs& a, hipStream_t st) {
     if (a.ra) bytes += 2.0 * a.N * (double)a.H * a.W * a.Ca * (a.ra_rs == 1 ? 0.25 : (a.ra_rs == 2 ? 4.0 : 1.0));
     if (a.rb) bytes += 2.0 * a.N * (double)a.H * a.W * (a.Cout - a.Ca);
     const bool halo = a.taps == 9 && a.src.rs != 2 && a.W >= 16 && a.H >= 4 && a.Cin % 16 == 0 && !g_force_gather &&
-                      (size_t)(HT_H + 2) * (HT_W + 2) * (a.Cin * 2 + 16) <= 150 * 1024;
+                      (size_t)(HT_H + 2) * (HT_W + 2) * (a.Cin * 2 + 16) <= 150 * 1024 && a.Cin <= AFF_MAXC;
     char tag[64] = "";
     if (prof_tags_on())
         snprintf(tag, sizeof(tag), "ci%d co%d %dx%d rs%d a%d r%d res%d%s", a.Cin, a.Cout, a.H, a.W, a.src.rs, a.src.scale != nullptr,

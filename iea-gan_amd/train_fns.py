@@ -59,7 +59,8 @@ class _Replay:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             ops.reset_zero_pool()          # every zero-filled scratch chunk must be filled INSIDE the graph ...
-            with torch.cuda.graph(g):
+            # thread_local: the RCCL watchdog thread polls its events while we capture; only this thread's calls are checked
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self.out = self.fn()
             ops.reset_zero_pool()          # ... and eager code must never carve from graph-owned memory
             self.graph = g
