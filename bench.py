@@ -193,7 +193,7 @@ def main():
         ridge = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)          # ~312 FLOP/B
         pmc = {}
         try:      # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, corrected)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["families"]
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_final_pmc_traffic.json")))["families"]
         except Exception:
             pass
 

@@ -14,48 +14,55 @@ __global__ __launch_bounds__(256) void conv_1toC_kernel(const float* __restrict_
                                                         const float* __restrict__ w, const float* __restrict__ bias,
                                                         bf16* __restrict__ out, int N, int H, int W, int flip) {
     constexpr int G = C / 8;
-    __shared__ float ws[9 * C];
-    for (int i = threadIdx.x; i < 9 * C; i += 256) ws[i] = w[i];
-    __syncthreads();
-    const long chunks = (long)N * H * W * G;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < chunks; idx += (long)gridDim.x * 256) {
-        const int cg = (int)(idx % G);
-        const long p = idx / G;
-        const int x = (int)(p % W);
-        const long t = p / W;
-        const int y = (int)(t % H);
-        const long nb = (t / H) * H * W;
+    // 256 % G == 0 and the grid stride is a multiple of 256: a thread keeps its channel group for every chunk it
+    // visits, so its 9 x 8 weights and 8 biases live in registers (no LDS / L1 traffic inside the loop)
+    const int cg = threadIdx.x % G;
+    float wr[9][8], br[8];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wr[tap][i] = w[(flip ? 8 - tap : tap) * C + cg * 8 + i];     // flip: correlate with the rotated kernel
+#pragma unroll
+    for (int i = 0; i < 8; ++i) br[i] = bias ? bias[cg * 8 + i] : 0.f;
+    const unsigned HW = (unsigned)H * W;
+    const unsigned pixels = (unsigned)N * HW;                    // < 2^31 (checked by the launcher)
+    const unsigned pstride = gridDim.x * (256 / G);
+    for (unsigned p = blockIdx.x * (256 / G) + threadIdx.x / G; p < pixels; p += pstride) {
+        const unsigned n = p / HW, rem = p - n * HW;
+        const int y = (int)(rem / W), x = (int)(rem - (unsigned)y * W);
+        const float* im = img + (size_t)n * HW;
+        const float* ty_ = tanh_y ? tanh_y + (size_t)n * HW : nullptr;
         float acc[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = bias ? bias[cg * 8 + i] : 0.f;
+        for (int i = 0; i < 8; ++i) acc[i] = br[i];
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-            const int yy = flip ? y - dy : y + dy, xx = flip ? x - dx : x + dx;
+            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
             float v = 0.f;
             if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-                v = img[nb + (long)yy * W + xx];
-                if (tanh_y) {
-                    const float ty = tanh_y[nb + (long)yy * W + xx];
+                v = im[yy * W + xx];
+                if (ty_) {
+                    const float ty = ty_[yy * W + xx];
                     v *= 1.f - ty * ty;
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] += v * ws[tap * C + cg * 8 + i];
+            for (int i = 0; i < 8; ++i) acc[i] = fmaf(v, wr[tap][i], acc[i]);
         }
         bf16x8 o;
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = f2bf(acc[i]);
-        *(bf16x8*)(out + idx * 8) = o;
+        *(bf16x8*)(out + ((size_t)p * G + cg) * 8) = o;
     }
 }
 
 extern "C" int ieagan_conv_1toC(const float* img, const float* tanh_y, const float* w, const float* bias, void* out, int N,
                                 int H, int W, int C, int flip, void* stream) {
     hipStream_t st = (hipStream_t)stream;
+    CHECK_ARG((long)N * H * W < (1L << 31), "conv_1toC: more than 2^31 pixels");
     ProfScope prof("conv_1toC", 18.0 * N * H * W * (double)C, (double)N * H * W * (4.0 + 2.0 * C), st);
     long blocks = ((long)N * H * W * (C / 8) + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
+    if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
 #define L(CC) hipLaunchKernelGGL((conv_1toC_kernel<CC>), dim3((unsigned)blocks), dim3(256), 0, st, img, tanh_y, w, bias, (bf16*)out, N, H, W, flip)
     if (C == 16) L(16);
