@@ -76,6 +76,7 @@ _SIGS = {
     "ieagan_diffaug_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, vp],
     "ieagan_diffaug_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, vp],
     "ieagan_cr_diffaug": [vp, vp, vp, vp, vp, i, i, i, vp],
+    "ieagan_event_ingest": [vp, vp, vp, i, i, i, i, f, vp],
     "ieagan_adam_step": [vp, vp, vp, vp, l, vp, vp],
     "ieagan_ema_update": [vp, vp, l, vp, vp],
     "ieagan_maxpool2_fwd": [vp, vp, vp, i, i, i, i, vp],

@@ -124,7 +124,15 @@ __global__ __launch_bounds__(256) void conv_Cto1_kernel(const bf16* __restrict__
         if (live && cg == 0) {
             float r = acc + (bias ? bias[0] : 0.f);
             if (tanh_out) r = tanhf(r);
-            out[p] = r;
+            if (tanh_out == 2) {        // detector-unit export (model.py:1140-1148): threshold, 256^((r+1)/2) - 1, clamp, crop 3 rows
+                if (y >= 3 && y < H - 3) {
+                    r = (r > -0.26f) ? r : -1.f;
+                    const float adu = fminf(fmaxf(exp2f(8.f * (r * 0.5f + 0.5f)) - 1.f, 0.f), 255.f);
+                    out[((long)n * (H - 6) + (y - 3)) * W + xw] = adu;
+                }
+            } else {
+                out[p] = r;
+            }
         }
     }
 }

@@ -233,7 +233,8 @@ class Generator(nn.Module):
                           stack_dst_flat=torch.tensor([r * sw[0].shape[1] for r in rows], dtype=torch.int64, device=dev))
         return self._plan
 
-    def forward(self, z, y, rdof=None):
+    def forward(self, z, y, rdof=None, export=False):
+        """``export=True`` (inference): returns detector units [N, H-6, W] straight from the last kernel (see ``generate``)."""
         plan = self._prepare()
         recs = plan["bank"].run(self.training, self.SN_eps)
         N = y.size(0)
@@ -255,6 +256,10 @@ class Generator(nn.Module):
         bn_out, conv_out = self.output_layer[0], self.output_layer[2]
         Nn, Hh, Ww, _ = xa.shape
         s, t = bn_out.scale_shift(st, Nn * Hh * Ww)
+        if export:
+            if torch.is_grad_enabled() and any(p.requires_grad for p in (conv_out.weight,)) and xa.requires_grad:
+                raise RuntimeError("Generator(export=True) is an inference path: call it under torch.no_grad()")
+            return ops.output_conv_export(xa, s, t, recs["output_layer.2"], conv_out.bias)
         return ops.OutputConvFn.apply(xa, s, t, conv_out.weight, conv_out.bias, recs["output_layer.2"])
 
 
@@ -479,11 +484,15 @@ class Model(Generator):
 
 
 def generate(model):
-    """One event of 40 sensor images in detector units: [40, 250, 768] (reference model.py:1130-1148)."""
+    """One event of 40 sensor images in detector units: [40, 250, 768] (reference model.py:1130-1148).  With this
+    package's Generator the threshold / 256^x / clamp / crop run inside the last conv kernel and only the finished
+    event crosses PCIe; any other callable takes the reference's host-side post-processing."""
     device = next(model.parameters()).device
     with torch.no_grad():
         latents = torch.randn(40, 128, device=device)
         labels = torch.arange(40, dtype=torch.long, device=device)
+        if isinstance(model, Generator):
+            return model(latents, labels, export=True).cpu()
         imgs = model(latents, labels).detach().cpu()
         imgs = F.threshold(imgs, -0.26, -1)            # cut the noise below 7 ADU
         imgs = imgs.mul_(0.5).add_(0.5)

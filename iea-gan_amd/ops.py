@@ -695,6 +695,16 @@ class OutputConvFn(torch.autograd.Function):
         return dh, dscale, dshift, dW, dbias, None
 
 
+def output_conv_export(h, scale, shift, rec, bias):
+    """G.output_layer fused with the export of ``model.generate``: BN apply + ReLU + conv + tanh + threshold +
+    256^((x+1)/2) - 1 + clamp + crop -> detector units, fp32 [N, H-6, W] (inference only, no autograd)."""
+    N, Hh, Ww, C = h.shape
+    out = torch.empty(N, Hh - 6, Ww, dtype=torch.float32, device=h.device)
+    H.call("ieagan_conv_Cto1", h.data_ptr(), scale.data_ptr(), shift.data_ptr(), 0, 1, rec.w_plain.data_ptr(), H.ptr(bias),
+           out.data_ptr(), 2, N, Hh, Ww, C, 0, H.stream())
+    return out
+
+
 # =====================================================================================================
 # module-boundary layout changes
 # =====================================================================================================

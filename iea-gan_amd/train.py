@@ -73,17 +73,14 @@ def synthetic_event(n, h, w, seed):
 
 
 def to_network_range(ev: torch.Tensor, res_h: int) -> torch.Tensor:
-    """uint8 [40, 250(+), W] ADC counts -> float32 [40, 1, res_h, W] in [-1, 1] (pad, lognorm255, noise, normalise)."""
-    x = ev.float()
+    """uint8 [40, 250(+), W] ADC counts -> float32 [40, 1, res_h, W] in [-1, 1]: the reference's pad / lognorm255 / noise /
+    normalise chain as one HIP kernel (``utils.ingest_event``); float events are taken as already normalised."""
     if ev.dtype == torch.uint8:
-        x = x / 255.0
-        pad = res_h - x.shape[1]
-        if pad > 0:
-            x = torch.nn.functional.pad(x, (0, 0, pad // 2, pad - pad // 2))
-        x = torch.log(255.0 * x + 1.0) / math.log(256.0)
-        x = x + 4e-3 * torch.rand_like(x)
-        x = (x - 0.5) / 0.5
-    return x.unsqueeze(1).contiguous()
+        pad = res_h - ev.shape[1]
+        if pad < 0 or pad % 2:
+            raise ValueError(f"event height {ev.shape[1]} cannot be padded symmetrically to {res_h}")
+        return utils.ingest_event(ev, pad=pad // 2)
+    return ev.float().unsqueeze(1).contiguous()
 
 
 def run(cfg):
@@ -136,7 +133,7 @@ def run(cfg):
             if G_ema is not None:
                 G_ema.train()
             ev = mine[i] if isinstance(mine[i], np.ndarray) else np.load(mine[i])
-            x = to_network_range(torch.from_numpy(ev).to(dev), h)
+            x = to_network_range(torch.from_numpy(ev), h).to(dev)
             metrics = train(x, y)
             if log is not None:
                 rec = dict(itr=state["itr"], **metrics)

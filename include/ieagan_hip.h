@@ -105,6 +105,8 @@ int ieagan_channel_stats(const void* x, float* stats, long P, int C, void* strea
  * G.output_layer = bn + relu + conv + tanh (model.py:379-387, 487) -------------------------------- */
 int ieagan_conv_1toC(const float* img, const float* tanh_y, const float* w, const float* bias, void* out,
                      int N, int H, int W, int C, int flip, void* stream);
+/* tanh_out: 0 = linear, 1 = tanh, 2 = tanh + the detector-unit export of model.generate (model.py:1139-1147:
+ * threshold(-0.26 -> -1), 256^((r+1)/2) - 1, clamp to [0, 255], rows 3 .. H-4 only): out is then fp32 [N, H-6, W]. */
 int ieagan_conv_Cto1(const void* x, const float* scale, const float* shift, int nstride, int relu,
                      const float* w, const float* bias, float* out, int tanh_out, int N, int H, int W, int C,
                      int flip, void* stream);
@@ -169,6 +171,11 @@ int ieagan_diffaug_bwd(const float* gout, const float* contrast, const long* tx,
                        const long* oy, float* gsums, float* gx, int N, int H, int W, void* stream);
 int ieagan_cr_diffaug(const float* x, const float* flip_u, const long* tx, const long* ty, float* out, int N,
                       int H, int W, void* stream);
+/* Event ingestion (reference utils/dataloader.py:66-77, utils/norm.py:9-20, utils/noise.py:29-32): uint8 [N,Hin,W] ->
+ * zero-pad `pad` rows top and bottom -> log(u + 1)/log(256) -> + scale * noise (explicit U[0,1) draws, fp32 [N,Hin+2pad,W],
+ * or NULL) -> (v - 0.5)/0.5 = fp32 [N, 1, Hin + 2 pad, W]. */
+int ieagan_event_ingest(const void* ev_u8, const float* noise, float* out, int N, int Hin, int W, int pad, float scale,
+                        void* stream);
 /* hp: device float[8] = {lr, beta1, beta2, eps, step, grad scale, -, -}; the launcher increments step and
  * derives the bias corrections on the device, so a captured HIP graph of the step stays valid. */
 int ieagan_adam_step(float* p, const float* g, float* m, float* v, long n, float* hp, void* stream);

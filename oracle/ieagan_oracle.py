@@ -490,6 +490,37 @@ def _clip(grads: Dict[str, Tensor], max_norm: float) -> None:
 # --------------------------------------------------------------------------------------------
 # export step after the path                                   (model.py:1130-1148)
 # --------------------------------------------------------------------------------------------
+def ingest_event(ev_u8: Tensor, noise: Optional[Tensor] = None, scale: float = 4e-3, pad: int = 3) -> Tensor:
+    """The ImageEventsDataset transform chain on one event (utils/dataloader.py:66-77): ``ev_u8`` uint8 [N, Hin, W] ->
+    Pad((0, 3, 0, 3)) -> ToTensor (/255) -> fn_lognorm255 (utils/norm.py:9-20) -> UniformNoise(4e-3) with the draws
+    ``noise`` ~ U[0,1) of the padded shape given explicitly (utils/noise.py:29-32) -> Normalize((0.5,), (0.5,))
+    -> fp32 [N, 1, Hin + 6, W]."""
+    t = F.pad(ev_u8.to(torch.float32) / 255.0, (0, 0, pad, pad))
+    t = torch.log(255 * t + 1) / math.log(256)
+    if noise is not None:
+        t = t + scale * noise.reshape(t.shape)
+    return ((t - 0.5) / 0.5).unsqueeze(1)
+
+
+def frechet_distance(mu1, sigma1, mu2, sigma2, eps: float = 1e-6) -> float:
+    """|mu1 - mu2|^2 + Tr(S1) + Tr(S2) - 2 Tr(sqrtm(S1 S2)) in numpy / scipy double precision
+    (mycleanfid/fid.py:431-468, incl. its eps-on-the-diagonal retry and the real-part rule)."""
+    import numpy as np
+    from scipy import linalg
+    mu1, mu2 = np.atleast_1d(mu1), np.atleast_1d(mu2)
+    sigma1, sigma2 = np.atleast_2d(sigma1), np.atleast_2d(sigma2)
+    diff = mu1 - mu2
+    covmean, _ = linalg.sqrtm(sigma1.dot(sigma2), disp=False)
+    if not np.isfinite(covmean).all():
+        offset = np.eye(sigma1.shape[0]) * eps
+        covmean = linalg.sqrtm((sigma1 + offset).dot(sigma2 + offset))
+    if np.iscomplexobj(covmean):
+        if not np.allclose(np.diagonal(covmean).imag, 0, atol=1e-3):
+            raise ValueError("Imaginary component {}".format(np.max(np.abs(covmean.imag))))
+        covmean = covmean.real
+    return float(diff.dot(diff) + np.trace(sigma1) + np.trace(sigma2) - 2 * np.trace(covmean))
+
+
 def generate_export(img: Tensor) -> Tensor:
     img = F.threshold(img, -0.26, -1)
     img = img * 0.5 + 0.5

@@ -508,3 +508,27 @@ def test_nonlocal_glue_maxpool_and_gamma_residual(dev):
     close(o.grad, 0.37 * d.float(), 8e-3, "gamma residual d_o")
     assert torch.equal(xx.grad, d), "gamma residual dx"
     close(gamma.grad, (d.float() * o.detach().float()).sum(), 1e-4, "gamma residual dgamma")
+
+
+def test_event_ingest_and_frechet_distance(dev, golden_dir):
+    """uint8 event -> network input (one kernel) and the device-side Frechet distance vs the reference-generated vectors."""
+    import ieagan_oracle as O
+    import utils
+    g = np.load(os.path.join(golden_dir, "op_ingest.npz"))
+    ev, u = torch.from_numpy(g["ev"]), torch.from_numpy(g["u"])
+    out = utils.ingest_event(ev, noise=u.reshape(5, 16, 16))            # host uint8 in, device fp32 out
+    assert out.is_cuda and out.shape == (5, 1, 16, 16)
+    close(out, torch.from_numpy(g["out"]), 2e-6, "ingest (golden)")
+    big = (torch.rand(40, 250, 768) < 0.01).to(torch.uint8) * torch.randint(1, 256, (40, 250, 768), dtype=torch.uint8)
+    x = utils.ingest_event(big.to(dev))
+    assert x.shape == (40, 1, 256, 768) and float(x.min()) >= -1.0 and float(x.max()) <= 1.0 + 8e-3
+    close(utils.ingest_event(big.to(dev), noise=False), O.ingest_event(big), 2e-6, "ingest 40x250x768 (oracle)")
+    assert float((x[:, :, :3] + 1).abs().max()) <= 8e-3 + 1e-6            # padded rows: -1 + dequantisation noise only
+
+    f = np.load(os.path.join(golden_dir, "op_frechet.npz"))
+    for name, (p, q) in {"ab": ("a", "b"), "aa": ("a", "a"), "ac": ("a", "c")}.items():
+        m1, s1 = utils.feature_statistics(torch.from_numpy(f[p]).to(dev))
+        m2, s2 = utils.feature_statistics(torch.from_numpy(f[q]).to(dev))
+        fd = utils.frechet_distance(m1, s1, m2, s2)
+        ref = float(f["fd_" + name])
+        assert abs(fd - ref) <= 1e-5 * max(1.0, abs(ref)), (name, fd, ref)

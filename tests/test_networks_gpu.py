@@ -55,6 +55,17 @@ def test_generator_eval_mode_and_export(golden_dir):
     with torch.no_grad():
         ref = O.generator(gsd, cfg, z.cpu(), torch.arange(40), rdof.cpu(), False)
     assert rel_l2(out, ref) <= TOL["G_rel_l2"]
+    # fused export epilogue (tanh -> threshold -> 256^((x+1)/2) - 1 -> clamp -> crop) vs the oracle's export of the
+    # product's own tanh output: same conv, so only the epilogue arithmetic is compared
+    with torch.no_grad():
+        adu = G(z, torch.arange(40).cuda(), rdof=rdof, export=True)
+    exp = O.generate_export(out.cpu())
+    assert adu.shape == exp.shape == (40, 58, 64)
+    assert float(adu.min()) >= 0.0 and float(adu.max()) <= 255.0
+    diff = (adu.cpu() - exp).abs()
+    assert float((diff > 1e-3 * (1.0 + exp.abs())).float().mean()) < 1e-4, float(diff.max())   # (threshold-edge pixels may flip)
+    ev = model.generate(G)
+    assert ev.shape == (40, 58, 64) and ev.device.type == "cpu" and torch.isfinite(ev).all()
 
 
 def test_full_resolution_properties():

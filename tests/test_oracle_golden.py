@@ -294,3 +294,17 @@ def test_train_step_64(golden_dir, ref_cfg, tag, clip, moved):
         assert torch.allclose(asums, g[f"{name}_abssum"], rtol=1e-4, atol=1e-3), name
     n_moved = sum(int(not torch.equal(gsd[k].detach(), g0[k])) for k in gp)
     assert n_moved == moved == int(g["G_params_moved"])
+
+
+def test_ingest_and_frechet_against_reference_vectors(golden_dir):
+    """Event ingestion chain and the Frechet distance (fixtures written by tests/golden/make_golden_io.py from the
+    reference's fn_lognorm255 / UniformNoise / frechet_distance)."""
+    g = _load(golden_dir, "op_ingest.npz")
+    out = O.ingest_event(g["ev"], g["u"])
+    _close(out, g["out"], 1e-6)
+    assert out.shape == (5, 1, 16, 16) and float(out.min()) >= -1.0 and float(out.max()) <= 1.0 + 8e-3
+    f = np.load(os.path.join(golden_dir, "op_frechet.npz"))
+    for name, (p, q) in {"ab": ("a", "b"), "aa": ("a", "a"), "ac": ("a", "c")}.items():
+        a, b = f[p], f[q]
+        fd = O.frechet_distance(a.mean(0), np.cov(a, rowvar=False), b.mean(0), np.cov(b, rowvar=False))
+        assert abs(fd - float(f["fd_" + name])) <= 1e-8 * max(1.0, abs(fd)), name
