@@ -135,7 +135,11 @@ def test_train_entry_point_config_merge(tmp_path):
                        "--ema", "false", "--max_iters", "2", "--device", "cuda"])
     assert cfg["resolution"] == 64 and cfg["H_base"] == 1 and cfg["G_lr"] == 1e-4 and cfg["clip_norm"] == 1e9
     assert cfg["ema"] is False and cfg["synthetic"] == 3 and cfg["D_lr"] == 5e-5
-    x = train.to_network_range(torch.from_numpy(train.synthetic_event(40, 58, 64, 1)), 64)
-    assert x.shape == (40, 1, 64, 64) and x.min() >= -1.0 and x.max() <= 1.01
+    ev = torch.from_numpy(train.synthetic_event(40, 58, 64, 1))
+    assert ev.dtype == torch.uint8 and ev.shape == (40, 58, 64)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):          # ingestion is a HIP kernel: it must fail loudly here
+        train.to_network_range(ev, 64)
+    xf = train.to_network_range(torch.zeros(40, 64, 64), 64)            # float events are taken as already normalised
+    assert xf.shape == (40, 1, 64, 64)
     with pytest.raises(SystemExit):
         train.parse(["--no_such_option", "1"])
