@@ -137,8 +137,9 @@ def test_train_entry_point_config_merge(tmp_path):
     assert cfg["ema"] is False and cfg["synthetic"] == 3 and cfg["D_lr"] == 5e-5
     ev = torch.from_numpy(train.synthetic_event(40, 58, 64, 1))
     assert ev.dtype == torch.uint8 and ev.shape == (40, 58, 64)
-    with pytest.raises(RuntimeError, match="no CPU fallback"):          # ingestion is a HIP kernel: it must fail loudly here
-        train.to_network_range(ev, 64)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU fallback"):      # ingestion is a HIP kernel: it must fail loudly here
+            train.to_network_range(ev, 64)
     xf = train.to_network_range(torch.zeros(40, 64, 64), 64)            # float events are taken as already normalised
     assert xf.shape == (40, 1, 64, 64)
     with pytest.raises(SystemExit):
