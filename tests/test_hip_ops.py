@@ -306,7 +306,7 @@ def test_single_channel_convs(dev, C, Hh, Ww):
     sc2, sh2 = scale.detach().clone().requires_grad_(True), shift.detach().clone().requires_grad_(True)
     Wp, b2 = Wv.detach().requires_grad_(True), bias.detach().clone().requires_grad_(True)
     y = ops.OutputConvFn.apply(ha, sc2, sh2, Wp, b2, rec)
-    close(y, ref, 2e-3, "output conv")
+    close(y, ref, 1e-2, "output conv")          # MFMA form: transformed activations and weights are bf16 operands, as in every other conv
     g = torch.autograd.grad((y * go).sum(), [ha, sc2, sh2, Wp, b2])
     for n, a, b in zip(("h", "scale", "shift", "W", "bias"), g, gref):
         close(nchw(a) if n == "h" else a, b, 2e-2, f"output conv grad {n}")
