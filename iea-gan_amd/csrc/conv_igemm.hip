@@ -345,7 +345,7 @@ static int launch_gather_pro(const ConvArgs& a, hipStream_t st) {
 #define HT_W 32
 
 template <bool AFF, bool RELU, int RS, int NT, int PF, int CIN>
-__global__ __launch_bounds__(256, (CIN >= 64 ? 2 : 1)) void conv3x3_halo_kernel(ConvArgs a, int tiles_w, int tiles_h, int ntiles, int tpb, int nblk) {
+__global__ __launch_bounds__(256, ((CIN >= 64 && PF == 0) ? 2 : 1)) void conv3x3_halo_kernel(ConvArgs a, int tiles_w, int tiles_h, int ntiles, int tpb, int nblk) {
     extern __shared__ __attribute__((aligned(16))) char smem_all[];
     __shared__ float red[4 * NT * 16 * 2];
     constexpr int AW = HT_W + 2, AH = HT_H + 2;
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(256, (CIN >= 64 ? 2 : 1)) void conv3x3_halo_kernel(
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfrag[nt], acc[mt][nt], 0, 0, 0);
             }
         };
-        if constexpr (CIN >= 64 && PF == 0) {
+        if constexpr (CIN >= 32) {
             // MFMA-bound layers: straight-line K loop with an explicit one-step-ahead software pipeline -- the weight
             // fragments (global / L1) and the pixel fragments (LDS) of step ks+1 are requested before the 4*NT MFMAs of
             // step ks issue; the scheduling barrier keeps the compiler from hoisting more loads (and registers) than that.
@@ -549,7 +549,10 @@ __global__ __launch_bounds__(256, (CIN >= 64 ? 2 : 1)) void conv3x3_halo_kernel(
             const unsigned wlane = (unsigned)(lr * KP + lg * 8) * 2u;
             auto ldb = [&](int ks, bf16x8(&b)[NT]) {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) b[nt] = *(const bf16x8*)(wnt[nt] + wlane + (unsigned)(ks * 64));
+                for (int nt = 0; nt < NT; ++nt) {
+                    if (PF > 0) b[nt] = *(const bf16x8*)(smem_all + (nt * 16 + lr) * WS + (ks * 32 + lg * 8) * 2);     // LDS-resident weights
+                    else b[nt] = *(const bf16x8*)(wnt[nt] + wlane + (unsigned)(ks * 64));
+                }
             };
             auto lda = [&](int ks, bf16x8(&x)[4]) {
                 const int tap = (ks * 32) / CIN, c0 = (ks * 32) % CIN;
@@ -611,7 +614,8 @@ static int launch_halo_nt(const ConvArgs& a, hipStream_t st) {
         size_t lds = halo;                                                                                   \
         const size_t epi = (size_t)4 * EpiLds<NTV>::FLOATS * 4;                                              \
         if (epi > lds) lds = epi;                                                                            \
-        const int tp = (PFV) > 0 ? tpb : 1;                                                                  \
+        int tp = (PFV) > 0 ? tpb : 1;                                                                        \
+        if ((PFV) > 0 && (CINV) >= 64) { tp = (ntiles + 255) / 256; if (tp > 8) tp = 8; }   /* one persistent block per CU */ \
         if ((PFV) > 0) lds += (size_t)NTV * 16 * (a.Kpad * 2 + 16);                                          \
         const int nblk = (ntiles + tp - 1) / tp;                                                             \
         hipLaunchKernelGGL((conv3x3_halo_kernel<AFF, RELU, RS, NTV, PFV, CINV>), dim3(nblk, (a.Cout + 16 * NTV - 1) / (16 * NTV)), \
@@ -630,6 +634,9 @@ static int launch_halo_nt(const ConvArgs& a, hipStream_t st) {
     else if (a.Cin == 32 && a.Cout == 32) HALO_LAUNCH(2, 6, 32)
     // (C = 64 with LDS-resident weights + prefetch was measured SLOWER -- 195-245 vs 270-320 TFLOP/s: one block of
     //  4 waves per CU leaves the ds_read -> MFMA latency exposed; it needs a hand-pipelined K loop first.)
+    // C = 64 on large maps: weights resident in LDS (one persistent block per CU, next halo prefetched into registers):
+    // 478 vs 343 TFLOP/s at 64x192 -- the per-wave 16-byte weight fetches through L1 were the limiter
+    else if (a.Cin == 64 && a.Cout == 64 && ntiles >= 1024) HALO_LAUNCH(4, 11, 64)
     else if (a.Cin == 64 && a.Cout % 64 == 0 && !small) HALO_LAUNCH(4, 0, 64)
     else if (a.Cin == 128 && a.Cout % 64 == 0 && !small) HALO_LAUNCH(4, 0, 128)
     else if (a.Cin == 128 && a.Cout % 32 == 0 && !(small && ntiles * (a.Cout / 32) < 512)) HALO_LAUNCH(2, 0, 128)

@@ -154,6 +154,35 @@ def test_halo_and_gather_kernels_agree(dev):
     close(outs[0][1], outs[1][1], 1e-3, "halo vs gather stats")
 
 
+@pytest.mark.parametrize("N,Hh,Ww,C", [(40, 64, 192, 64),      # LDS-resident weights, persistent blocks (>= 1024 tiles)
+                                       (6, 32, 96, 64),        # C = 64 with weights through L1, pipelined K loop
+                                       (4, 16, 48, 128),       # C = 128
+                                       (8, 128, 96, 32),       # C = 32: prefetching variant, unrolled K loop
+                                       (4, 100, 70, 16)])      # C = 16: prefetching variant, ragged tiles
+def test_specialised_halo_variants_agree_with_gather(dev, N, Hh, Ww, C):
+    """Every channel-specialised 3x3 kernel (compile-time K loop, software pipeline, LDS weights, register prefetch of the
+    next tile) against the plain gather kernel on the same operands, with a ReLU prologue, a ReLU-mask epilogue and statistics."""
+    import _hip, ops
+    torch.manual_seed(9)
+    x = torch.randn(N, Hh, Ww, C, device=dev).to(BF)
+    kpad = ops._kpad(9 * C)
+    w = torch.zeros(C, kpad, device=dev)
+    w[:, :9 * C] = torch.randn(C, 9 * C, device=dev) / math.sqrt(9 * C)
+    w = w.to(BF)
+    bias = 0.1 * torch.randn(C, device=dev)
+    mask = torch.randn(N, Hh, Ww, C, device=dev).to(BF)
+    outs = []
+    for force in (0, 1):
+        _hip.call("ieagan_conv_force_gather", force)
+        out = torch.empty(N, Hh, Ww, C, device=dev, dtype=BF)
+        st = ops.new_stats(C, dev)
+        ops._conv_launch(x, C, Hh, Ww, 0, None, None, 0, True, N, Hh, Ww, C, C, 9, kpad, w, bias, None, 0, 0, 0, None, 0, mask, out, st)
+        outs.append((out, st.sum(0)))
+    _hip.call("ieagan_conv_force_gather", 0)
+    close(outs[0][0], outs[1][0], 4e-3, "halo vs gather out")
+    close(outs[0][1], outs[1][1], 2e-3, "halo vs gather stats")
+
+
 def conv_reference(x, W, u, bias, scale, shift, relu, rs, taps, ra, ra_mode, Ca, rb):
     """fp32 NCHW composite with the kernel's rounding points (A operand and weights in bf16)."""
     a = x
