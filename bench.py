@@ -52,7 +52,7 @@ def bench_config():
     return cfg
 
 
-def cpu_baseline(cfg, sensors=4, threads=None):
+def cpu_baseline(cfg, sensors=8, threads=None):
     """The oracle's train step at full 256x768 resolution on `sensors` of the 40 sensors of one event
     (BN / RRM / losses over that sub-event), scaled by 40/sensors: bounded to tens of seconds."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
