@@ -102,15 +102,16 @@ struct EpiLds {
     static constexpr int FLOATS = 32 * LDW;
 };
 
-template <int NT, typename PixFn>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x4 (&acc)[2][NT], float* wlds, int n_base, PixFn pix,
+template <int NT, int MTS = 2, typename PixFn>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x4 (&acc)[MTS][NT], float* wlds, int n_base, PixFn pix,
                                               float (&s1)[8], float (&s2)[8]) {
     constexpr int LDW = EpiLds<NT>::LDW;
     constexpr int CPP = NT * 2;                         // 8-channel chunks per pixel
+    static_assert((16 * MTS * CPP) % 64 == 0, "epilogue rows x chunks must fill whole waves");
     const int lane = threadIdx.x & 63;
     const int lr = lane & 15, lg = lane >> 4;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MTS; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -124,7 +125,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x4 (&a
     for (int i = 0; i < 8; ++i) bv[i] = (a.bias && ch_ok) ? a.bias[co0 + i] : 0.f;
     const int H = a.H, W = a.W;
 #pragma unroll
-    for (int it = 0; it < (32 * CPP) / 64; ++it) {
+    for (int it = 0; it < (16 * MTS * CPP) / 64; ++it) {
         const int row = (it * 64 + lane) / CPP;
         long m;
         int n, h, w;
@@ -218,8 +219,10 @@ __device__ __forceinline__ void stats_flush(const ConvArgs& a, float (&s1)[8], f
 // A fragments gathered straight from global memory (any H, W; 1x1 and small 3x3 layers).
 // ------------------------------------------------------------------------------------------------
 template <int TAPS, bool AFF, bool RELU, int RS, int NT, bool LAFF>
-__global__ __launch_bounds__(256) void conv_gather_kernel(ConvArgs a) {
-    __shared__ __attribute__((aligned(16))) float epi[4 * EpiLds<NT>::FLOATS];
+__global__ __launch_bounds__(256, 4) void conv_gather_kernel(ConvArgs a) {
+    // NT >= 2: the epilogue transposes 16 pixel rows at a time (half the LDS -> more resident blocks for this latency-bound kernel)
+    constexpr int EROWS = (NT >= 2) ? 16 : 32;
+    __shared__ __attribute__((aligned(16))) float epi[4 * EROWS * EpiLds<NT>::LDW];
     __shared__ float red[4 * NT * 16 * 2];
     __shared__ __attribute__((aligned(32))) float aff_s[LAFF ? 2 * AFF_MAXC : 8];   // LAFF: all 128 pixels of a block share one image
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -295,7 +298,16 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(ConvArgs a) {
         }
         return true;
     };
-    conv_epilogue<NT>(a, acc, epi + wave * EpiLds<NT>::FLOATS, n_base, pix, s1, s2);
+    if constexpr (NT >= 2) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            auto pixh = [&](int row, long& m, int& n, int& h, int& w) -> bool { return pix(row + 16 * half, m, n, h, w); };
+            const f32x4(&sub)[1][NT] = *reinterpret_cast<const f32x4(*)[1][NT]>(&acc[half]);
+            conv_epilogue<NT, 1>(a, sub, epi + wave * EROWS * EpiLds<NT>::LDW, n_base, pixh, s1, s2);
+        }
+    } else {
+        conv_epilogue<NT>(a, acc, epi + wave * EROWS * EpiLds<NT>::LDW, n_base, pix, s1, s2);
+    }
     if (a.stats != nullptr) stats_flush<NT>(a, s1, s2, n_base, red, blockIdx.x);
 }
 
