@@ -357,7 +357,7 @@ static int launch_gather_pro(const ConvArgs& a, hipStream_t st) {
 #define HT_W 32
 
 template <bool AFF, bool RELU, int RS, int NT, int PF, int CIN>
-__global__ __launch_bounds__(256, ((CIN >= 64 && PF == 0) ? 2 : 1)) void conv3x3_halo_kernel(ConvArgs a, int tiles_w, int tiles_h, int ntiles, int tpb, int nblk) {
+__global__ __launch_bounds__(256, ((CIN >= 64 && PF == 0) ? 2 : (CIN == 16 ? 4 : (CIN == 32 ? 3 : 1)))) void conv3x3_halo_kernel(ConvArgs a, int tiles_w, int tiles_h, int ntiles, int tpb, int nblk) {
     extern __shared__ __attribute__((aligned(16))) char smem_all[];
     __shared__ float red[4 * NT * 16 * 2];
     constexpr int AW = HT_W + 2, AH = HT_H + 2;
@@ -742,7 +742,7 @@ __device__ __forceinline__ bf16x8 frag_T(const bf16* lds, int row0_bytes_unused,
 }
 
 template <int TAPS, bool AFF, bool RELU, int RS, int MT, bool TR>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+__global__ __launch_bounds__(256, (TR ? (MT == 4 ? 3 : (MT == 8 ? 2 : 1)) : 1)) void conv_wgrad_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int HALO = (TAPS == 9) ? 1 : 0;
     constexpr int AW = WG_TW + 2 * HALO, AH = WG_TH + 2 * HALO;
