@@ -242,37 +242,84 @@ __global__ __launch_bounds__(256) void nl_attn_bwd_k_kernel(const bf16* __restri
 #pragma unroll
     for (int nt = 0; nt < DV / 16; ++nt) dv[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     dk[0] = dk[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int qc = 0; qc < Lq; qc += AT_CH) {
-        __syncthreads();
-        stage_rows(dolds, dOn, qc, Lq, DV);
-        for (int idx = threadIdx.x; idx < AT_CH * 4; idx += 256) {
-            const int r = idx >> 2, c = idx & 3;
-            bf16x8 v = zero8();
-            if (qc + r < Lq && c * 8 < dqk) v = *(const bf16x8*)(Qn + (long)(qc + r) * dqk + c * 8);
-            *(bf16x8*)(qlds + r * 32 + c * 8) = v;
+    // The 480 blocks of this kernel cannot hide memory latency behind each other (< 2 per CU), so every global operand of
+    // chunk c+1 -- the A fragments of Q and dO, the rows staged into LDS for the transposed reads, LSE and delta -- is
+    // requested into registers before chunk c is computed.
+    constexpr int SD = (AT_CH * DV / 8) / 256;                     // dO staging chunks per thread (1 / 1 / 2 for DV 32 / 64 / 128)
+    static_assert(SD >= 1 || DV == 32, "staging split");
+    constexpr int SDN = SD > 0 ? SD : 1;
+    bf16x8 qa_n[2], da_n[2][DV / 32], sdo_n[SDN], sq_n;
+    float lse_n[2][4], dlt_n[2][4];
+    auto prefetch = [&](int qc) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const long qrow = qc + 16 * t + lr;
+            qa_n[t] = rowfrag(Qn, qrow, Lq, dqk, lg);
+#pragma unroll
+            for (int s = 0; s < DV / 32; ++s) {
+                da_n[t][s] = zero8();
+                if (qrow < Lq) da_n[t][s] = *(const bf16x8*)(dOn + qrow * DV + 32 * s + 8 * lg);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long q = qc + 16 * t + 4 * lg + r;
+                lse_n[t][r] = (q < Lq) ? LSE[n * Lq + q] : 0.f;
+                dlt_n[t][r] = (q < Lq) ? delta[n * Lq + q] : 0.f;
+            }
         }
+#pragma unroll
+        for (int j = 0; j < SDN; ++j) {
+            const int idx = threadIdx.x + j * 256;
+            const int r = idx / (DV / 8), c = idx - r * (DV / 8);
+            sdo_n[j] = zero8();
+            if (idx < AT_CH * (DV / 8) && qc + r < Lq) sdo_n[j] = *(const bf16x8*)(dOn + (long)(qc + r) * DV + c * 8);
+        }
+        {
+            const int r = threadIdx.x >> 2, c = threadIdx.x & 3;
+            sq_n = zero8();
+            if (threadIdx.x < AT_CH * 4 && qc + r < Lq && c * 8 < dqk) sq_n = *(const bf16x8*)(Qn + (long)(qc + r) * dqk + c * 8);
+        }
+    };
+    prefetch(0);
+    for (int qc = 0; qc < Lq; qc += AT_CH) {
+        bf16x8 qa[2], da[2][DV / 32];
+        float lse[2][4], dlt[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            qa[t] = qa_n[t];
+#pragma unroll
+            for (int s = 0; s < DV / 32; ++s) da[t][s] = da_n[t][s];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                lse[t][r] = lse_n[t][r];
+                dlt[t][r] = dlt_n[t][r];
+            }
+        }
+        __syncthreads();                                           // the previous chunk's transposed reads are done
+#pragma unroll
+        for (int j = 0; j < SDN; ++j) {
+            const int idx = threadIdx.x + j * 256;
+            const int r = idx / (DV / 8), c = idx - r * (DV / 8);
+            if (idx < AT_CH * (DV / 8)) *(bf16x8*)(dolds + r * DV + c * 8) = sdo_n[j];
+        }
+        if (threadIdx.x < AT_CH * 4) *(bf16x8*)(qlds + (threadIdx.x >> 2) * 32 + (threadIdx.x & 3) * 8) = sq_n;
         __syncthreads();
+        if (qc + AT_CH < Lq) prefetch(qc + AT_CH);                 // in flight during this chunk's MFMAs
         f32x4 p[2], ds[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {                              // tile t: rows = queries qc+16t.., cols = keys
-            const long qrow = qc + 16 * t + lr;
-            const bf16x8 qa = rowfrag(Qn, qrow, Lq, dqk, lg);
-            p[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            p[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[t], kf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             ds[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < DV / 32; ++s) {                    // dP tile: rows = queries, cols = keys
-                bf16x8 da = zero8();
-                if (qrow < Lq) da = *(const bf16x8*)(dOn + qrow * DV + 32 * s + 8 * lg);
-                ds[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[s], ds[t], 0, 0, 0);
-            }
+            for (int s = 0; s < DV / 32; ++s)                      // dP tile: rows = queries, cols = keys
+                ds[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da[t][s], vf[s], ds[t], 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const long q = qc + 16 * t + 4 * lg + r;           // query (row) of this accumulator element
                 const bool ok = q < Lq && k0 + lr < Lk;
-                const float pr = ok ? __expf(p[t][r] - LSE[n * Lq + q]) : 0.f;
-                const float dlt = ok ? delta[n * Lq + q] : 0.f;
+                const float pr = ok ? __expf(p[t][r] - lse[t][r]) : 0.f;
                 p[t][r] = pr;                                      // P[q][key lr]
-                ds[t][r] = pr * (ds[t][r] - dlt);                  // dS[q][key lr]
+                ds[t][r] = pr * (ds[t][r] - (ok ? dlt[t][r] : 0.f));   // dS[q][key lr]
             }
         }
         const bf16x8 pa = pack2(p[0], p[1]);                       // A: [key lr][k-slot (g,j) = query pi(g,j)]
