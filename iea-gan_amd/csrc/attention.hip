@@ -75,16 +75,36 @@ __global__ __launch_bounds__(256) void nl_attn_fwd_kernel(const bf16* __restrict
     f32x4 o[DV / 16];
 #pragma unroll
     for (int nt = 0; nt < DV / 16; ++nt) o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int kc = 0; kc < Lk; kc += AT_CH) {
-        __syncthreads();
-        stage_rows(vlds, Vn, kc, Lk, DV);
-        __syncthreads();
-        f32x4 s[2];
+    // operands of key chunk c+1 (K fragments, the V rows staged for the transposed reads) are requested into registers
+    // before chunk c is computed
+    constexpr int SV = (AT_CH * DV / 8 + 255) / 256;               // V staging chunks per thread
+    bf16x8 kf_n[2], sv_n[SV];
+    auto prefetch = [&](int kc) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {                              // S^T tile t: rows = keys kc+16t.., cols = queries
-            const bf16x8 kf = rowfrag(Kn, kc + 16 * t + lr, Lk, dqk, lg);
-            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        for (int t = 0; t < 2; ++t) kf_n[t] = rowfrag(Kn, kc + 16 * t + lr, Lk, dqk, lg);
+#pragma unroll
+        for (int j = 0; j < SV; ++j) {
+            const int idx = threadIdx.x + j * 256;
+            const int r = idx / (DV / 8), c = idx - r * (DV / 8);
+            sv_n[j] = zero8();
+            if (idx < AT_CH * (DV / 8) && kc + r < Lk) sv_n[j] = *(const bf16x8*)(Vn + (long)(kc + r) * DV + c * 8);
         }
+    };
+    prefetch(0);
+    for (int kc = 0; kc < Lk; kc += AT_CH) {
+        const bf16x8 kf0 = kf_n[0], kf1 = kf_n[1];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SV; ++j) {
+            const int idx = threadIdx.x + j * 256;
+            const int r = idx / (DV / 8), c = idx - r * (DV / 8);
+            if (idx < AT_CH * (DV / 8)) *(bf16x8*)(vlds + r * DV + c * 8) = sv_n[j];
+        }
+        __syncthreads();
+        if (kc + AT_CH < Lk) prefetch(kc + AT_CH);
+        f32x4 s[2];                                                // S^T tile t: rows = keys kc+16t.., cols = queries
+        s[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        s[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         float cm = -1e30f;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -167,30 +187,46 @@ __global__ __launch_bounds__(256) void nl_attn_bwd_q_kernel(const bf16* __restri
     const float lse = (q0 + lr < Lq) ? LSE[n * Lq + q0 + lr] : 0.f;
     if (lg == 0 && q0 + lr < Lq) delta[n * Lq + q0 + lr] = dl;
     f32x4 dq[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-    for (int kc = 0; kc < Lk; kc += AT_CH) {
-        __syncthreads();
-        {   // K chunk [32 keys][32] (zero padded beyond dqk) for the transposed reads of the dQ product
-            for (int idx = threadIdx.x; idx < AT_CH * 4; idx += 256) {
-                const int r = idx >> 2, c = idx & 3;
-                bf16x8 v = zero8();
-                if (kc + r < Lk && c * 8 < dqk) v = *(const bf16x8*)(Kn + (long)(kc + r) * dqk + c * 8);
-                *(bf16x8*)(klds + r * 32 + c * 8) = v;
-            }
-        }
-        __syncthreads();
-        f32x4 p[2], dp[2];
+    // operands of key chunk c+1 (A fragments of K and V, the K rows staged for the transposed reads) are requested
+    // into registers before chunk c is computed
+    bf16x8 kf_n[2], vf_n[2][DV / 32], sk_n;
+    auto prefetch = [&](int kc) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const long krow = kc + 16 * t + lr;
-            const bf16x8 kf = rowfrag(Kn, krow, Lk, dqk, lg);
-            p[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            kf_n[t] = rowfrag(Kn, krow, Lk, dqk, lg);
+#pragma unroll
+            for (int s = 0; s < DV / 32; ++s) {
+                vf_n[t][s] = zero8();
+                if (krow < Lk) vf_n[t][s] = *(const bf16x8*)(Vn + krow * DV + 32 * s + 8 * lg);
+            }
+        }
+        const int r = threadIdx.x >> 2, c = threadIdx.x & 3;
+        sk_n = zero8();
+        if (threadIdx.x < AT_CH * 4 && kc + r < Lk && c * 8 < dqk) sk_n = *(const bf16x8*)(Kn + (long)(kc + r) * dqk + c * 8);
+    };
+    prefetch(0);
+    for (int kc = 0; kc < Lk; kc += AT_CH) {
+        bf16x8 kfc[2], vfc[2][DV / 32];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            kfc[t] = kf_n[t];
+#pragma unroll
+            for (int s = 0; s < DV / 32; ++s) vfc[t][s] = vf_n[t][s];
+        }
+        __syncthreads();
+        // K chunk [32 keys][32] (zero padded beyond dqk) for the transposed reads of the dQ product
+        if (threadIdx.x < AT_CH * 4) *(bf16x8*)(klds + (threadIdx.x >> 2) * 32 + (threadIdx.x & 3) * 8) = sk_n;
+        __syncthreads();
+        if (kc + AT_CH < Lk) prefetch(kc + AT_CH);
+        f32x4 p[2], dp[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            p[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfc[t], qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             dp[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < DV / 32; ++s) {                    // dP^T tile: rows = keys, cols = queries
-                bf16x8 vf = zero8();
-                if (krow < Lk) vf = *(const bf16x8*)(Vn + krow * DV + 32 * s + 8 * lg);
-                dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[s], dp[t], 0, 0, 0);
-            }
+            for (int s = 0; s < DV / 32; ++s)                      // dP^T tile: rows = keys, cols = queries
+                dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfc[t][s], dof[s], dp[t], 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const bool ok = kc + 16 * t + 4 * lg + r < Lk;
