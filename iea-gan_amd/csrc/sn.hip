@@ -51,23 +51,39 @@ __global__ __launch_bounds__(256) void sn_phase1_kernel(const long* __restrict__
     }
 }
 
-// fold the row-chunk partials: one block per (layer, 256-column tile)
+// fold the row-chunk partials: one block per (layer, 32-column tile); 8 threads share a column (fixed split, ordered
+// combine -> still bit-reproducible), so G.linear's 768 partials per column are 96-long chains instead of 768-long
+#define SN_CB 32
 __global__ __launch_bounds__(256) void sn_phase1b_kernel(const long* __restrict__ tab, const int* __restrict__ cblocks,
                                                          const float* __restrict__ part, float* __restrict__ ctx) {
+    __shared__ float sub[8][SN_CB];
     const long* L = tab + (long)cblocks[2 * blockIdx.x] * SN_FIELDS;
-    const int i = cblocks[2 * blockIdx.x + 1] + threadIdx.x;
+    const int col = threadIdx.x % SN_CB, part_id = threadIdx.x / SN_CB;
+    const int i = cblocks[2 * blockIdx.x + 1] + col;
     const int out = (int)L[F_OUT], in = (int)L[F_IN];
-    if (i >= in) return;
     const int chunks = (out + SN_ROWS - 1) / SN_ROWS;
-    const float* src = part + L[F_PART] + i;
+    const int per = (chunks + 7) / 8;
     float s = 0.f;
-    for (int c = 0; c < chunks; ++c) s += src[(long)c * in];
-    ctx[L[F_CTX] + 8 + out + i] = s;
+    if (i < in) {
+        const float* src = part + L[F_PART] + i;
+        const int c1 = min(chunks, (part_id + 1) * per);
+        for (int c = part_id * per; c < c1; ++c) s += src[(long)c * in];
+    }
+    sub[part_id][col] = s;
+    __syncthreads();
+    if (part_id == 0 && i < in) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += sub[k][col];
+        ctx[L[F_CTX] + 8 + out + i] = t;
+    }
 }
 
 __global__ __launch_bounds__(256) void sn_phase2_kernel(const long* __restrict__ tab, const int* __restrict__ blocks,
-                                                        const float* __restrict__ params, float* __restrict__ ctx, float eps) {
+                                                        const float* __restrict__ params, float* __restrict__ ctx, float* __restrict__ part,
+                                                        float eps) {
     __shared__ float red[4];
+    __shared__ float tsq[4];
     const long* L = tab + (long)blocks[2 * blockIdx.x] * SN_FIELDS;
     const int row0 = blocks[2 * blockIdx.x + 1];
     const int out = (int)L[F_OUT], in = (int)L[F_IN];
@@ -83,17 +99,24 @@ __global__ __launch_bounds__(256) void sn_phase2_kernel(const long* __restrict__
         for (int i = threadIdx.x; i < in; i += 256) v[i] = vraw[i] * inv;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r1 = min(row0 + SN_ROWS, out);
+    float sq = 0.f;
     for (int o = row0 + wave; o < r1; o += 4) {
         float s = 0.f;
         for (int i = lane; i < in; i += 64) s += W[(long)o * in + i] * (vraw[i] * inv);
         s = wave_sum(s);
+        sq += s * s;
         if (lane == 0) c[8 + out + 2 * in + o] = s;            // t[o]; phase 3 turns it into u'
     }
+    // |t|^2 of this block's rows (fixed order): phase 3 then folds out/32 partials instead of re-reading all of t in every
+    // block (24576 floats x 768 blocks for G.linear).  The phase-1 partial buffer is free again at this point.
+    if (lane == 0) tsq[wave] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) part[L[F_PART] + row0 / SN_ROWS] = (tsq[0] + tsq[1]) + (tsq[2] + tsq[3]);
 }
 
 __global__ __launch_bounds__(256) void sn_phase3_kernel(const long* __restrict__ tab, const int* __restrict__ blocks,
-                                                        float* __restrict__ params, float* __restrict__ ctx, char* __restrict__ pack,
-                                                        float eps, int training) {
+                                                        float* __restrict__ params, float* __restrict__ ctx, const float* __restrict__ part,
+                                                        char* __restrict__ pack, float eps, int training) {
     const long* L = tab + (long)blocks[2 * blockIdx.x] * SN_FIELDS;
     const int row0 = blocks[2 * blockIdx.x + 1];
     const int out = (int)L[F_OUT], in = (int)L[F_IN], taps = (int)L[F_TAPS], cin = (int)L[F_CIN], kind = (int)L[F_KIND];
@@ -103,7 +126,8 @@ __global__ __launch_bounds__(256) void sn_phase3_kernel(const long* __restrict__
     __shared__ float red3[4];
     const float* tvec = c + 8 + out + 2 * in;
     float tt = 0.f;
-    for (int o = threadIdx.x; o < out; o += 256) tt += tvec[o] * tvec[o];     // same order in every block
+    const int chunks = (out + SN_ROWS - 1) / SN_ROWS;
+    for (int ch = threadIdx.x; ch < chunks; ch += 256) tt += part[L[F_PART] + ch];     // same order in every block
     tt = block_sum(tt, red3);
     const float un = fmaxf(sqrtf(tt), eps);
     const float sigma = tt / un;
@@ -162,8 +186,8 @@ extern "C" int ieagan_sn_forward(const long* tab, const int* blocks, int nblocks
     ProfScope prof("sn_forward", 0.0, 0.0, st);
     hipLaunchKernelGGL(sn_phase1_kernel, dim3(nblocks), dim3(256), 0, st, tab, blocks, (const float*)params, part);
     hipLaunchKernelGGL(sn_phase1b_kernel, dim3(ncblocks), dim3(256), 0, st, tab, cblocks, (const float*)part, ctx);
-    hipLaunchKernelGGL(sn_phase2_kernel, dim3(nblocks), dim3(256), 0, st, tab, blocks, (const float*)params, ctx, eps);
-    hipLaunchKernelGGL(sn_phase3_kernel, dim3(nblocks), dim3(256), 0, st, tab, blocks, params, ctx, (char*)pack, eps, training);
+    hipLaunchKernelGGL(sn_phase2_kernel, dim3(nblocks), dim3(256), 0, st, tab, blocks, (const float*)params, ctx, part, eps);
+    hipLaunchKernelGGL(sn_phase3_kernel, dim3(nblocks), dim3(256), 0, st, tab, blocks, params, ctx, (const float*)part, (char*)pack, eps, training);
     CHECK_LAUNCH("sn_forward");
     return 0;
 }

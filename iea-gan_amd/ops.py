@@ -219,7 +219,7 @@ class SNBank:
             part_off += nchunk * inn
             for r0 in range(0, out, self.ROWS):
                 blocks.append([i, r0])
-            for c0 in range(0, inn, 256):
+            for c0 in range(0, inn, 32):          # SN_CB columns per phase-1b block (csrc/sn.hip)
                 cblocks.append([i, c0])
         self.ctx_size, self.pack_size, self.part_size = ctx_off, pack_off, part_off
         self.table = torch.tensor(rows, dtype=torch.int64, device=dev)
