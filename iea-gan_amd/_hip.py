@@ -34,7 +34,7 @@ class ConvDesc(C.Structure):
 class WgradDesc(C.Structure):
     _fields_ = [("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
                 ("taps", C.c_int), ("Kpad", C.c_int), ("src", SrcDesc), ("g", vp), ("Cg", C.c_int),
-                ("dw", vp), ("tiles_per_block", C.c_int)]
+                ("dw", vp), ("tiles_per_block", C.c_int), ("colsum", vp)]
 
 
 class ProfRec(C.Structure):

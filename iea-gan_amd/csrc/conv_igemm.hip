@@ -779,6 +779,8 @@ __global__ __launch_bounds__(256, (TR ? (MT == 4 ? 3 : (MT == 8 ? 2 : 1)) : 1)) 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    const bool do_colsum = a.colsum != nullptr && blockIdx.y == 0;      // one n-tile group per (pixel, cout) tile does it
+    float csum = 0.f;
     const long tile_begin = (long)blockIdx.x * a.tiles_per_block;
     long tile_end = tile_begin + a.tiles_per_block;
     if (tile_end > tiles_total) tile_end = tiles_total;
@@ -803,6 +805,9 @@ __global__ __launch_bounds__(256, (TR ? (MT == 4 ? 3 : (MT == 8 ? 2 : 1)) : 1)) 
             *(bf16x8*)(lds_a + hp * Cin + cc * 8) = v;
         }
         __syncthreads();
+        if (do_colsum) {      // bias gradient: column sums of the staged g tile (thread = column t % GC, pixel phase t / GC)
+            for (int px = threadIdx.x / GC; px < WG_TH * WG_TW; px += 256 / GC) csum += bf2f(lds_g[px * GC + (threadIdx.x % GC)]);
+        }
         // ---- 4 k-steps of 32 pixels (two tile rows each); lane group lg owns 8 consecutive pixels
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -817,6 +822,17 @@ __global__ __launch_bounds__(256, (TR ? (MT == 4 ? 3 : (MT == 8 ? 2 : 1)) : 1)) 
                 for (int mt = 0; mt < MT; ++mt)
                     acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfr, acc[mt][j], 0, 0, 0);
             }
+        }
+    }
+    if (do_colsum) {          // fold the 256 / GC pixel phases of a column through LDS, one atomic per column per block
+        __syncthreads();
+        float* red = (float*)smem;
+        red[threadIdx.x] = csum;
+        __syncthreads();
+        if (threadIdx.x < GC && cout0 + threadIdx.x < a.Cout) {
+            float t = 0.f;
+            for (int ph = 0; ph < 256 / GC; ++ph) t += red[ph * GC + threadIdx.x];
+            atomicAdd(a.colsum + (long)(blockIdx.x % STAT_REPL) * a.Cout + cout0 + threadIdx.x, t);
         }
     }
     // ---- accumulate into dWp[cout][k]

@@ -520,6 +520,7 @@ class ConvFn(torch.autograd.Function):
         P = N * Hc * Wc
         # ---- fold the batch-statistics path of the following BN into the out-grad; bias gradient
         dbias = None
+        colsum_in_wgrad = False
         if dstats is not None:
             geff = torch.empty_like(g)
             colsum = None
@@ -530,7 +531,10 @@ class ConvFn(torch.autograd.Function):
             g = geff
         elif has_bias and need[2]:
             colsum = sn_scratch(rec, "b", (STAT_REPL, Cout), dev) if need[1] else zeros((STAT_REPL, Cout), dev)
-            H.call("ieagan_effgrad", g.data_ptr(), None, None, None, colsum.data_ptr(), P, Cout, H.stream())
+            if need[1]:
+                colsum_in_wgrad = True      # the wgrad kernel stages every g tile anyway: it takes the column sums along
+            else:
+                H.call("ieagan_effgrad", g.data_ptr(), None, None, None, colsum.data_ptr(), P, Cout, H.stream())
         # ---- residual operands
         d_ra = d_rb = None
         if has_ra and need[5]:
@@ -597,7 +601,8 @@ class ConvFn(torch.autograd.Function):
         if need[1]:
             dwp = sn_scratch(rec, "w", (Cout, rec.kpad), dev)
             d = H.WgradDesc(N, Hc, Wc, Cin, Cout, taps, rec.kpad,
-                            H.src_desc(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu), g.data_ptr(), Cout, dwp.data_ptr(), 0)
+                            H.src_desc(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu), g.data_ptr(), Cout, dwp.data_ptr(), 0,
+                            H.ptr(colsum) if colsum_in_wgrad else None)
             H.call("ieagan_conv_wgrad", d, int(USE_TR_READ), H.stream())
             dW, dbias = sn_backward(dwp, weight, rec, colsum if (has_bias and need[2]) else None, ctx.bias_ref)
         elif has_bias and need[2]:

@@ -74,6 +74,8 @@ typedef struct {
     int Cg;
     float* dw;            /* fp32 [Cout][Kpad], caller zeroes                                   */
     int tiles_per_block;  /* filled by the launcher                                             */
+    float* colsum;        /* optional fp32 [32][Cout], caller-zeroed replicas: += column sums of g (the
+                           * bias gradient), taken from the g tiles the kernel stages anyway           */
 } ieagan_wgrad_desc;
 int ieagan_conv_wgrad(const ieagan_wgrad_desc* d, int use_tr_read, void* stream);
 
