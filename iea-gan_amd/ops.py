@@ -516,7 +516,16 @@ class ConvFn(torch.autograd.Function):
         Cout, Cin = rec.out, rec.cin
         dev = x.device
         need = ctx.needs_input_grad
-        g = dout.contiguous()
+        # The out-grad may be a channel slice of a wider NHWC tensor (concat shortcut of a D block): the dgrad / wgrad kernels
+        # take a row stride, so only the statistics / effgrad paths need a packed copy.
+        Cg = Cout
+        st = dout.stride()
+        sliced = (not dout.is_contiguous() and st[3] == 1 and st[2] % 8 == 0 and st[2] >= Cout and st[1] == Wc * st[2]
+                  and st[0] == Hc * Wc * st[2] and dout.data_ptr() % 16 == 0)
+        if sliced and dstats is None and not (has_bias and need[2] and not need[1]) and not (has_ra and need[5]) and not (has_rb and need[6]):
+            g, Cg = dout, st[2]
+        else:
+            g = dout.contiguous()
         P = N * Hc * Wc
         # ---- fold the batch-statistics path of the following BN into the out-grad; bias gradient
         dbias = None
@@ -567,19 +576,19 @@ class ConvFn(torch.autograd.Function):
             if res_in is not None and (fuse_mask or (plain and rs == 0)):
                 # bare-ReLU / no prologue (D blocks): the dgrad epilogue masks the main path and adds the
                 # shortcut gradient (0.25 * nearest-expand when the shortcut was average-pooled)
-                _conv_launch(g, Cout, Hc, Wc, 0, None, None, 0, False, N, Hc, Wc, Cout, Cin, taps, rec.kpad2, rec.w_bwd, None,
+                _conv_launch(g, Cg, Hc, Wc, 0, None, None, 0, False, N, Hc, Wc, Cout, Cin, taps, rec.kpad2, rec.w_bwd, None,
                              lg, lC, lCa, 1 if lmode == 2 else 0, None, 0, x if fuse_mask else None, da, None,
                              ra_scale=0.25 if lmode == 2 else 1.0)
                 dx = da
             elif res_in is not None and plain and rs == 2 and res_out is None:
                 # conv_sc of a D block (pooled, un-activated input): chain -- add the deposited shortcut
                 # gradient at the pooled resolution and re-deposit the sum for the block's first conv
-                _conv_launch(g, Cout, Hc, Wc, 0, None, None, 0, False, N, Hc, Wc, Cout, Cin, taps, rec.kpad2, rec.w_bwd, None,
+                _conv_launch(g, Cg, Hc, Wc, 0, None, None, 0, False, N, Hc, Wc, Cout, Cin, taps, rec.kpad2, rec.w_bwd, None,
                              lg, lC, lCa, 0, None, 0, None, da, None)
                 res_in.deposit(da, Cin, Cin, 2)
                 dx = None
             else:
-                _conv_launch(g, Cout, Hc, Wc, 0, None, None, 0, False, N, Hc, Wc, Cout, Cin, taps, rec.kpad2, rec.w_bwd, None,
+                _conv_launch(g, Cg, Hc, Wc, 0, None, None, 0, False, N, Hc, Wc, Cout, Cin, taps, rec.kpad2, rec.w_bwd, None,
                              None, 0, 0, 0, None, 0, x if fuse_mask else None, da, None)
                 if (fuse_mask or (plain and rs == 0)) and res_in is None:
                     dx = da
@@ -601,7 +610,7 @@ class ConvFn(torch.autograd.Function):
         if need[1]:
             dwp = sn_scratch(rec, "w", (Cout, rec.kpad), dev)
             d = H.WgradDesc(N, Hc, Wc, Cin, Cout, taps, rec.kpad,
-                            H.src_desc(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu), g.data_ptr(), Cout, dwp.data_ptr(), 0,
+                            H.src_desc(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu), g.data_ptr(), Cg, dwp.data_ptr(), 0,
                             H.ptr(colsum) if colsum_in_wgrad else None)
             H.call("ieagan_conv_wgrad", d, int(USE_TR_READ), H.stream())
             dW, dbias = sn_backward(dwp, weight, rec, colsum if (has_bias and need[2]) else None, ctx.bias_ref)
