@@ -741,7 +741,7 @@ __device__ __forceinline__ bf16x8 frag_T(const bf16* lds, int row0_bytes_unused,
     return f;
 }
 
-template <int TAPS, bool AFF, bool RELU, int RS, int MT, bool TR>
+template <int TAPS, bool AFF, bool RELU, int RS, int MT, bool TR, int NJ>
 __global__ __launch_bounds__(256, (TR ? (MT == 4 ? 3 : (MT == 8 ? 2 : 1)) : 1)) void conv_wgrad_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int HALO = (TAPS == 9) ? 1 : 0;
@@ -816,7 +816,7 @@ __global__ __launch_bounds__(256, (TR ? (MT == 4 ? 3 : (MT == 8 ? 2 : 1)) : 1)) 
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) af[mt] = frag_T<TR>(lds_g, 0, GC, row * WG_TW + col, mt * 16, lr);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NJ; ++j) {          // NJ = 1: layers with <= 4 n-tiles in total (1x1, Cin <= 64): one per wave
                 const bf16x8 bfr = frag_T<TR>(lds_a, 0, Cin, (row + t_dy[j]) * AW + col + t_dx[j], t_c0[j], lr);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
@@ -837,7 +837,7 @@ __global__ __launch_bounds__(256, (TR ? (MT == 4 ? 3 : (MT == 8 ? 2 : 1)) : 1)) 
     }
     // ---- accumulate into dWp[cout][k]
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         if (!t_ok[j]) continue;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -850,12 +850,19 @@ __global__ __launch_bounds__(256, (TR ? (MT == 4 ? 3 : (MT == 8 ? 2 : 1)) : 1)) 
 
 template <int TAPS, bool AFF, bool RELU, int RS, bool TR>
 static void launch_wgrad_mt(const WgradArgs& a, hipStream_t st, int mt, dim3 grid, size_t lds) {
-    switch (mt) {
-        case 1: hipLaunchKernelGGL((conv_wgrad_kernel<TAPS, AFF, RELU, RS, 1, TR>), grid, dim3(256), lds, st, a); break;
-        case 2: hipLaunchKernelGGL((conv_wgrad_kernel<TAPS, AFF, RELU, RS, 2, TR>), grid, dim3(256), lds, st, a); break;
-        case 4: hipLaunchKernelGGL((conv_wgrad_kernel<TAPS, AFF, RELU, RS, 4, TR>), grid, dim3(256), lds, st, a); break;
-        default: hipLaunchKernelGGL((conv_wgrad_kernel<TAPS, AFF, RELU, RS, 8, TR>), grid, dim3(256), lds, st, a); break;
+    const bool one = TAPS == 1 && TR && a.Cin <= 64;       // <= 4 n-tiles in total: every wave owns at most one
+#define WG_L(MTV)                                                                                                       \
+    {                                                                                                                   \
+        if (TAPS == 1 && TR && one) hipLaunchKernelGGL((conv_wgrad_kernel<TAPS, AFF, RELU, RS, MTV, TR, (TAPS == 1 && TR) ? 1 : 4>), grid, dim3(256), lds, st, a); \
+        else hipLaunchKernelGGL((conv_wgrad_kernel<TAPS, AFF, RELU, RS, MTV, TR, 4>), grid, dim3(256), lds, st, a);     \
     }
+    switch (mt) {
+        case 1: WG_L(1) break;
+        case 2: WG_L(2) break;
+        case 4: WG_L(4) break;
+        default: WG_L(8) break;
+    }
+#undef WG_L
 }
 
 template <int TAPS, int RS, bool TR>
