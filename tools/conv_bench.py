@@ -10,6 +10,9 @@ N, Hh, Ww, Cin, Cout, taps = map(int, sys.argv[1:7])
 relu = int(sys.argv[7]) if len(sys.argv) > 7 else 0
 mask = int(sys.argv[8]) if len(sys.argv) > 8 else 0
 iters = int(sys.argv[9]) if len(sys.argv) > 9 else 20
+aff = int(os.environ.get("CB_AFF", "0"))
+res = int(os.environ.get("CB_RES", "0"))          # 0 none, 1 same-res, 2 upsampled (half-res operand), 3 pooled (double-res operand)
+want_stats = int(os.environ.get("CB_STATS", "1"))
 H.require_gpu()
 dev = "cuda:0"
 x = torch.randn(N, Hh, Ww, Cin, device=dev).to(torch.bfloat16)
@@ -18,12 +21,21 @@ w = (torch.randn(Cout, kpad, device=dev) * 0.05).to(torch.bfloat16)
 bias = torch.randn(Cout, device=dev)
 out = torch.empty(N, Hh, Ww, Cout, device=dev, dtype=torch.bfloat16)
 mk = torch.randn(N, Hh, Ww, Cout, device=dev).to(torch.bfloat16) if mask else None
-stats = torch.zeros(32, 2, Cout, device=dev)
+stats = torch.zeros(32, 2, Cout, device=dev) if want_stats else None
+sc = (1 + 0.1 * torch.randn(N, Cin, device=dev)) if aff else None
+sh = (0.1 * torch.randn(N, Cin, device=dev)) if aff else None
+ra = None
+if res == 1:
+    ra = torch.randn(N, Hh, Ww, Cout, device=dev).to(torch.bfloat16)
+elif res == 2:
+    ra = torch.randn(N, Hh // 2, Ww // 2, Cout, device=dev).to(torch.bfloat16)
+elif res == 3:
+    ra = torch.randn(N, Hh * 2, Ww * 2, Cout, device=dev).to(torch.bfloat16)
 
 
 def run():
-    ops._conv_launch(x, Cin, Hh, Ww, 0, None, None, 0, bool(relu), N, Hh, Ww, Cin, Cout, taps, kpad, w, bias, None, 0, 0, 0, None, 0, mk, out,
-                     stats)
+    ops._conv_launch(x, Cin, Hh, Ww, 0, sc, sh, Cin if aff else 0, bool(relu), N, Hh, Ww, Cin, Cout, taps, kpad, w, bias, ra, Cout if ra is not None else 0,
+                     Cout if ra is not None else 0, max(res - 1, 0), None, 0, mk, out, stats)
 
 
 for _ in range(3):
@@ -38,4 +50,4 @@ torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3 / iters
 flops = 2.0 * N * Hh * Ww * Cout * taps * Cin
 byts = 2.0 * N * Hh * Ww * (Cin + Cout * (2 if mask else 1))
-print(f"conv {taps}tap N{N} {Hh}x{Ww} {Cin}->{Cout} relu{relu} mask{mask}: {us:.1f} us  {flops/us/1e6:.0f} TF  {byts/us/1e3:.0f} GB/s")
+print(f"conv {taps}tap N{N} {Hh}x{Ww} {Cin}->{Cout} relu{relu} mask{mask} aff{aff} res{res} stats{want_stats}: {us:.1f} us  {flops/us/1e6:.0f} TF  {byts/us/1e3:.0f} GB/s")
