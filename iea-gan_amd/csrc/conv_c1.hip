@@ -1,70 +1,115 @@
 // 3x3 convolutions with a single-channel image on one side:
 //   conv_1toC   image[N,H,W] fp32 -> NHWC bf16 [N,H,W,C]    D.input_conv forward (model.py:905) and the
-//                                                            dgrad of G's output conv (with tanh'); coalesced VALU,
-//                                                            thread = (pixel, 8-channel group), weights in registers
+//                                                            dgrad of G's output conv (with tanh'); K = 9 taps on MFMA
+//                                                            with the image split into bf16 high + low parts
 //   conv_Cto1   NHWC bf16 [N,H,W,C] -> image fp32            G.output_layer: BN apply + ReLU + conv + tanh (+ the
 //                                                            detector-unit export) (model.py:379-387,487,1139-1147) and
 //                                                            dgrad of D.input_conv; per-tap dot products on MFMA
-//   wgrad_c1    dW[tap][c] = sum_p img[p +/- d(tap)] * t[p,c]   (coalesced VALU)
+//   wgrad_c1    dW[tap][c] = sum_p img[p +/- d(tap)] * t[p,c]   taps x channels over K = pixels on MFMA
 #include "common.h"
 
-// w: fp32 [9][C].  img_mul (optional): the image is multiplied by (1 - y*y) first (tanh backward).
+// conv_1toC on the matrix cores.  out[p][c] = bias[c] + sum_tap img(p + d(tap)) * w[tap][c] is a GEMM with K = 9; one
+// 16x16x32 MFMA step carries it twice: k slots 0..8 hold the bf16 HIGH parts of the nine image values, k slots 16..24 their
+// bf16 LOW parts (img - hi), against the same weights in both halves -- the fp32 image is thus represented to ~16 mantissa
+// bits while the weights are bf16 operands as in every other conv.  Block = 8 x 32 output pixels, image halo in LDS,
+// accumulators transposed through LDS so that every lane stores 8 channels (16 bytes) of one pixel.
+// w: fp32 [9][C].  tanh_y (optional): the image is multiplied by (1 - y*y) first (tanh backward).
+#define I1_TH 8
+#define I1_TW 32
 template <int C>
 __global__ __launch_bounds__(256) void conv_1toC_kernel(const float* __restrict__ img, const float* __restrict__ tanh_y,
                                                         const float* __restrict__ w, const float* __restrict__ bias,
-                                                        bf16* __restrict__ out, int N, int H, int W, int flip) {
-    constexpr int G = C / 8;
-    // 256 % G == 0 and the grid stride is a multiple of 256: a thread keeps its channel group for every chunk it
-    // visits, so its 9 x 8 weights and 8 biases live in registers (no LDS / L1 traffic inside the loop)
-    const int cg = threadIdx.x % G;
-    float wr[9][8], br[8];
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) wr[tap][i] = w[(flip ? 8 - tap : tap) * C + cg * 8 + i];     // flip: correlate with the rotated kernel
-#pragma unroll
-    for (int i = 0; i < 8; ++i) br[i] = bias ? bias[cg * 8 + i] : 0.f;
-    const unsigned HW = (unsigned)H * W;
-    const unsigned pixels = (unsigned)N * HW;                    // < 2^31 (checked by the launcher)
-    const unsigned pstride = gridDim.x * (256 / G);
-    for (unsigned p = blockIdx.x * (256 / G) + threadIdx.x / G; p < pixels; p += pstride) {
-        const unsigned n = p / HW, rem = p - n * HW;
-        const int y = (int)(rem / W), x = (int)(rem - (unsigned)y * W);
-        const float* im = img + (size_t)n * HW;
-        const float* ty_ = tanh_y ? tanh_y + (size_t)n * HW : nullptr;
-        float acc[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = br[i];
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-            float v = 0.f;
-            if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-                v = im[yy * W + xx];
-                if (ty_) {
-                    const float ty = ty_[yy * W + xx];
-                    v *= 1.f - ty * ty;
-                }
+                                                        bf16* __restrict__ out, int N, int H, int W, int flip, int tiles_w,
+                                                        int tiles_h) {
+    constexpr int NT = C / 16;
+    constexpr int AW = I1_TW + 2, AH = I1_TH + 2;
+    constexpr int LDO = C + 4;                                   // padded fp32 row of the transposed output tile
+    __shared__ float halo[AH][AW + 2];
+    __shared__ __attribute__((aligned(16))) float ot[4][16 * LDO];   // per wave: one m-tile (16 pixels) x C channels
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int tile = blockIdx.x;
+    const int n = tile / (tiles_w * tiles_h);
+    const int trem = tile - n * tiles_w * tiles_h;
+    const int y0 = (trem / tiles_w) * I1_TH, x0 = (trem % tiles_w) * I1_TW;
+    const float* im = img + (size_t)n * H * W;
+    const float* ty_ = tanh_y ? tanh_y + (size_t)n * H * W : nullptr;
+    for (int i = threadIdx.x; i < AH * AW; i += 256) {
+        const int qy = i / AW, qx = i - qy * AW;
+        const int yy = y0 - 1 + qy, xx = x0 - 1 + qx;
+        float v = 0.f;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+            v = im[yy * W + xx];
+            if (ty_) {
+                const float t = ty_[yy * W + xx];
+                v *= 1.f - t * t;
             }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] = fmaf(v, wr[tap][i], acc[i]);
         }
-        bf16x8 o;
+        halo[qy][qx] = v;
+    }
+    // B fragments: B[k][cout lr]; k slots 8*lg + j: lg 0 -> taps 0..7, lg 1 -> tap 8 (j = 0), lg 2 / 3 the same again (low parts)
+    bf16x8 bfrag[NT];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = f2bf(acc[i]);
-        *(bf16x8*)(out + ((size_t)p * G + cg) * 8) = o;
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int tap = (lg & 1) * 8 + j;
+            float v = 0.f;
+            if (tap < 9) v = w[(flip ? 8 - tap : tap) * C + nt * 16 + lr];
+            bfrag[nt][j] = f2bf(v);
+        }
+    float bv[8];
+    const int cc = lane % (C / 8);                               // this lane's 8-channel chunk in the store phase
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bv[i] = bias ? bias[cc * 8 + i] : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {                             // wave: tile rows 2*wave, 2*wave+1 = 4 m-tiles of 16 pixels
+        const int ty = 2 * wave + (mi >> 1), tx0 = (mi & 1) * 16;
+        // A fragment: row = pixel lr of the m-tile; k slots of this lane group: image values at taps 8*(lg&1) + j
+        bf16x8 af;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int tap = (lg & 1) * 8 + j;
+            float v = 0.f;
+            if (tap < 9) v = halo[ty + tap / 3][tx0 + lr + tap % 3];
+            const bf16 hi = f2bf(v);
+            af[j] = (lg < 2) ? hi : f2bf(v - bf2f(hi));
+        }
+        float* o = ot[wave];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfrag[nt], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[(4 * lg + r) * LDO + nt * 16 + lr] = d[r];      // D[pixel 4lg+r][cout lr]
+        }
+        // wave-private buffer, LDS operations of one wave complete in order: read back as (pixel, 8-channel chunk) items
+#pragma unroll
+        for (int it = 0; it < (16 * (C / 8) + 63) / 64; ++it) {
+            const int item = it * 64 + lane;
+            if (item >= 16 * (C / 8)) break;
+            const int px = item / (C / 8);
+            const f32x4 lo = *(const f32x4*)(o + px * LDO + cc * 8);
+            const f32x4 hi = *(const f32x4*)(o + px * LDO + cc * 8 + 4);
+            const int y = y0 + ty, x = x0 + tx0 + px;
+            if (y < H && x < W) {
+                bf16x8 ov;
+                ov[0] = f2bf(lo[0] + bv[0]); ov[1] = f2bf(lo[1] + bv[1]); ov[2] = f2bf(lo[2] + bv[2]); ov[3] = f2bf(lo[3] + bv[3]);
+                ov[4] = f2bf(hi[0] + bv[4]); ov[5] = f2bf(hi[1] + bv[5]); ov[6] = f2bf(hi[2] + bv[6]); ov[7] = f2bf(hi[3] + bv[7]);
+                *(bf16x8*)(out + (((size_t)n * H + y) * W + x) * C + cc * 8) = ov;
+            }
+        }
     }
 }
 
 extern "C" int ieagan_conv_1toC(const float* img, const float* tanh_y, const float* w, const float* bias, void* out, int N,
                                 int H, int W, int C, int flip, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    CHECK_ARG((long)N * H * W < (1L << 31), "conv_1toC: more than 2^31 pixels");
     ProfScope prof("conv_1toC", 18.0 * N * H * W * (double)C, (double)N * H * W * (4.0 + 2.0 * C), st);
-    long blocks = ((long)N * H * W * (C / 8) + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    if (blocks < 1) blocks = 1;
-#define L(CC) hipLaunchKernelGGL((conv_1toC_kernel<CC>), dim3((unsigned)blocks), dim3(256), 0, st, img, tanh_y, w, bias, (bf16*)out, N, H, W, flip)
+    const int tiles_w = (W + I1_TW - 1) / I1_TW, tiles_h = (H + I1_TH - 1) / I1_TH;
+    const long blocks = (long)N * tiles_w * tiles_h;
+    CHECK_ARG(blocks > 0 && blocks < (1L << 31), "conv_1toC: bad geometry");
+#define L(CC) hipLaunchKernelGGL((conv_1toC_kernel<CC>), dim3((unsigned)blocks), dim3(256), 0, st, img, tanh_y, w, bias, (bf16*)out, N, H, W, flip, tiles_w, tiles_h)
     if (C == 16) L(16);
     else if (C == 32) L(32);
     else if (C == 64) L(64);
@@ -199,67 +244,126 @@ extern "C" int ieagan_conv_Cto1(const void* x, const float* scale, const float* 
 }
 
 // ------------------------------------------------------------------------------------------------
-// wgrad_c1: dw[tap][c] += sum_p imgval(p +/- d(tap)) * T(t[p,c]);  dw fp32 [9][C] (caller zeroes).
+// wgrad_c1 on the matrix cores: dw[tap][c] += sum_p imgval(p +/- d(tap)) * T(t[p, c]);  dw fp32 [9][C] (caller zeroes).
+// GEMM view: D[tap (16 rows, 9 used)][c] over K = pixels.  A = image patches (row = tap, k = 8 consecutive pixels of a tile
+// row, taken from an fp32 halo in LDS and split into bf16 high + low parts -> two MFMAs per n-tile), B = the transformed
+// t tile staged in its natural [pixel][C] layout and read pixel-major with ds_read_b64_tr_b16.  Block = persistent over
+// 8 x 32 pixel tiles; wave w owns tile rows 2w, 2w+1.  One atomic per (tap, c) per block at the end.
 // ------------------------------------------------------------------------------------------------
+#define W1_TH 8
+#define W1_TW 32
+__device__ __forceinline__ bf16x8 tr8(const bf16* lds, int stride_elems, int pix0, int col0, int lr) {
+    const int q = lr >> 2, p = lr & 3;
+    const bf16* p0 = lds + (pix0 + q) * stride_elems + col0 + 4 * p;
+    const bf16* p1 = p0 + 4 * stride_elems;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)p0);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)p1);
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+
 template <int C, bool AFF, bool RELU>
 __global__ __launch_bounds__(256) void wgrad_c1_kernel(const float* __restrict__ img, const float* __restrict__ tanh_y,
                                                        const bf16* __restrict__ t, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, int nstride, float* __restrict__ dw,
-                                                       int N, int H, int W, int flip) {
-    constexpr int G = C / 8;
-    __shared__ float red[256 * 8];
-    float acc[9][8];
+                                                       int N, int H, int W, int flip, int tiles_w, int tiles_h, int ntiles, int tpb) {
+    constexpr int NT = C / 16, CH = C / 8;
+    constexpr int AW = W1_TW + 2, AH = W1_TH + 2;
+    __shared__ float halo[AH][AW + 2];
+    __shared__ __attribute__((aligned(16))) bf16 tl[W1_TH * W1_TW * C];          // [pixel][C]
+    __shared__ float red[4][NT * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int sgn = flip ? -1 : 1;
+    const int dy = sgn * (lr / 3 - 1), dx = sgn * (lr % 3 - 1);                   // tap lr (rows 9..15 of A are zero)
+    const int cc = threadIdx.x % CH;                                             // staging: this thread's 8-channel chunk (256 % CH == 0)
+    float sc[8], sh[8];
+    int n_cur = -1;
+    f32x4 acc[NT];
 #pragma unroll
-    for (int a = 0; a < 9; ++a)
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int t0 = blockIdx.x * tpb, t1 = min(t0 + tpb, ntiles);
+    for (int tile = t0; tile < t1; ++tile) {
+        const int n = tile / (tiles_w * tiles_h);
+        const int trem = tile - n * tiles_w * tiles_h;
+        const int y0 = (trem / tiles_w) * W1_TH, x0 = (trem % tiles_w) * W1_TW;
+        if (AFF && n != n_cur) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[a][i] = 0.f;
-    const int cg = threadIdx.x % G;
-    const long chunks = (long)N * H * W * G;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < chunks; idx += (long)gridDim.x * 256) {
-        const long p = idx / G;
-        const int x = (int)(p % W);
-        const long tt = p / W;
-        const int y = (int)(tt % H);
-        const int n = (int)(tt / H);
-        const long nb = (long)n * H * W;
-        const bf16x8 v = *(const bf16x8*)(t + idx * 8);
-        float f[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            f[i] = bf2f(v[i]);
-            if (AFF) f[i] = f[i] * scale[(long)n * nstride + cg * 8 + i] + shift[(long)n * nstride + cg * 8 + i];
-            if (RELU) f[i] = fmaxf(f[i], 0.f);
+            for (int i = 0; i < 8; ++i) {
+                sc[i] = scale[(size_t)n * nstride + cc * 8 + i];
+                sh[i] = shift[(size_t)n * nstride + cc * 8 + i];
+            }
+            n_cur = n;
+        }
+        __syncthreads();                                         // previous tile's fragments consumed
+        const float* im = img + (size_t)n * H * W;
+        const float* ty_ = tanh_y ? tanh_y + (size_t)n * H * W : nullptr;
+        for (int i = threadIdx.x; i < AH * AW; i += 256) {
+            const int qy = i / AW, qx = i - qy * AW;
+            const int yy = y0 - 1 + qy, xx = x0 - 1 + qx;
+            float v = 0.f;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                v = im[yy * W + xx];
+                if (ty_) {
+                    const float q = ty_[yy * W + xx];
+                    v *= 1.f - q * q;
+                }
+            }
+            halo[qy][qx] = v;
         }
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-            const int yy = flip ? y - dy : y + dy, xx = flip ? x - dx : x + dx;
-            float iv = 0.f;
-            if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-                iv = img[nb + (long)yy * W + xx];
-                if (tanh_y) {
-                    const float ty = tanh_y[nb + (long)yy * W + xx];
-                    iv *= 1.f - ty * ty;
+        for (int j = 0; j < (W1_TH * W1_TW * CH) / 256; ++j) {
+            const int idx = threadIdx.x + j * 256;
+            const int px = idx / CH;                             // chunk index of this thread stays cc
+            const int yy = y0 + px / W1_TW, xx = x0 + px % W1_TW;
+            bf16x8 v = zero8();
+            if (yy < H && xx < W) {
+                v = *(const bf16x8*)(t + (((size_t)n * H + yy) * W + xx) * C + cc * 8);
+                if (AFF || RELU) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        float f = bf2f(v[i]);
+                        if (AFF) f = fmaf(f, sc[i], sh[i]);
+                        if (RELU) f = fmaxf(f, 0.f);
+                        v[i] = f2bf(f);
+                    }
+                }
+            }
+            *(bf16x8*)(tl + px * C + cc * 8) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int row = 2 * wave + rr;
+            bf16x8 ahi = zero8(), alo = zero8();
+            if (lr < 9) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v = halo[row + 1 + dy][8 * lg + j + 1 + dx];
+                    const bf16 h = f2bf(v);
+                    ahi[j] = h;
+                    alo[j] = f2bf(v - bf2f(h));
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[tap][i] += iv * f[i];
+            for (int nt = 0; nt < NT; ++nt) {
+                const bf16x8 b = tr8(tl, C, row * W1_TW + 8 * lg, nt * 16, lr);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, b, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo, b, acc[nt], 0, 0, 0);
+            }
         }
     }
-    // block reduce per tap by channel group, one atomic per (tap, c) per block
-    const int tid = threadIdx.x;
+    // D[tap 4lg + r][channel nt*16 + lr]: fold the four waves, one atomic per (tap, c) per block
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) red[tid * 8 + i] = acc[tap][i];
-        __syncthreads();
-        for (int o = tid; o < C; o += 256) {
-            const int g = o >> 3, i = o & 7;
-            float s = 0.f;
-            for (int u = g; u < 256; u += G) s += red[u * 8 + i];
-            atomicAdd(dw + tap * C + o, s);
-        }
-        __syncthreads();
+        for (int r = 0; r < 4; ++r) red[wave][nt * 256 + (4 * lg + r) * 16 + lr] = acc[nt][r];
+    __syncthreads();
+    for (int i = threadIdx.x; i < NT * 256; i += 256) {
+        const int nt = i / 256, tap = (i % 256) / 16, c = i % 16;
+        if (tap < 9) atomicAdd(dw + tap * C + nt * 16 + c, red[0][i] + red[1][i] + red[2][i] + red[3][i]);
     }
 }
 
@@ -267,12 +371,16 @@ extern "C" int ieagan_wgrad_c1(const float* img, const float* tanh_y, const void
                                int nstride, int relu, float* dw, int N, int H, int W, int C, int flip, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof("wgrad_c1", 18.0 * N * H * W * (double)C, (double)N * H * W * (4.0 + 2.0 * C), st);
-    long blocks = ((long)N * H * W * (C / 8) + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
-    if (blocks < 1) blocks = 1;
+    const int tiles_w = (W + W1_TW - 1) / W1_TW, tiles_h = (H + W1_TH - 1) / W1_TH;
+    const long ntl = (long)N * tiles_w * tiles_h;
+    CHECK_ARG(ntl > 0 && ntl < (1L << 31), "wgrad_c1: bad geometry");
+    const int ntiles = (int)ntl;
+    int tpb = (ntiles + 1023) / 1024;                 // <= 1024 blocks: every block ends with 9*C atomics on the same addresses
+    if (tpb < 1) tpb = 1;
+    const int blocks = (ntiles + tpb - 1) / tpb;
     const bool aff = scale != nullptr;
 #define L(CC, A, R) hipLaunchKernelGGL((wgrad_c1_kernel<CC, A, R>), dim3((unsigned)blocks), dim3(256), 0, st, img, tanh_y, (const bf16*)t, \
-                                       scale, shift, nstride, dw, N, H, W, flip)
+                                       scale, shift, nstride, dw, N, H, W, flip, tiles_w, tiles_h, ntiles, tpb)
 #define LC(CC)                        \
     if (aff && relu) L(CC, true, true); \
     else if (!aff && !relu) L(CC, false, false); \
