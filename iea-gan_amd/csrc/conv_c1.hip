@@ -83,7 +83,9 @@ __global__ __launch_bounds__(256) void conv_1toC_kernel(const float* __restrict_
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[(4 * lg + r) * LDO + nt * 16 + lr] = d[r];      // D[pixel 4lg+r][cout lr]
         }
-        // wave-private buffer, LDS operations of one wave complete in order: read back as (pixel, 8-channel chunk) items
+        // wave-private buffer: LDS operations of one wave complete in order, the fences keep the compiler from moving them
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int it = 0; it < (16 * (C / 8) + 63) / 64; ++it) {
             const int item = it * 64 + lane;
@@ -99,6 +101,8 @@ __global__ __launch_bounds__(256) void conv_1toC_kernel(const float* __restrict_
                 *(bf16x8*)(out + (((size_t)n * H + y) * W + x) * C + cc * 8) = ov;
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // the next m-tile overwrites the buffer
+        __builtin_amdgcn_wave_barrier();
     }
 }
 

@@ -179,25 +179,33 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x4 (&a
 
 // fold the per-lane statistics partials (lane owns channel chunk lane % (2*NT)) and add them to the
 // replicated statistics buffer: one atomic per channel per block.
+// The fold over the 64 / CPP lanes that share a chunk goes through a wave-private LDS matrix sx[16 values][64 lanes]
+// (XOR-swizzled columns): 16 stores + 64 / CPP loads per lane instead of a 16-value x log2(64 / CPP)-step shuffle
+// butterfly -- the flush was ~20 % of the instruction stream of the generator's 1x1 convolutions.
+#define STATS_SX_FLOATS (8 * 64)           // per wave (sums and sums of squares take turns)
 template <int NT>
 __device__ __forceinline__ void stats_flush(const ConvArgs& a, float (&s1)[8], float (&s2)[8], int n_base, float* red /*[4][NT*16][2]*/,
-                                            int replica) {
+                                            float* sx_all /* 4 * STATS_SX_FLOATS, free at this point */, int replica) {
     constexpr int CPP = NT * 2;
+    constexpr int SH = 64 / CPP;                      // lanes sharing a chunk
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* sx = sx_all + wave * STATS_SX_FLOATS;
+    // wave-private matrix: LDS operations of one wave execute in order, no barrier needed between the phases
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int w = 0; w < 2; ++w) {
 #pragma unroll
-        for (int o = CPP; o < 64; o <<= 1) {
-            s1[i] += __shfl_xor(s1[i], o, 64);
-            s2[i] += __shfl_xor(s2[i], o, 64);
+        for (int i = 0; i < 8; ++i) sx[i * 64 + (lane ^ i)] = w ? s2[i] : s1[i];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // make the wave's stores visible to its other lanes
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 8 * CPP) {                         // output (chunk cc, channel i of the chunk): 8 * CPP <= 64 per wave
+            const int cc = lane % CPP, i = lane / CPP;
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < SH; ++k) t += sx[i * 64 + ((cc + CPP * k) ^ i)];
+            red[(wave * NT * 16 + cc * 8 + i) * 2 + w] = t;
         }
-    }
-    if (lane < CPP) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            red[(wave * NT * 16 + lane * 8 + i) * 2 + 0] = s1[i];
-            red[(wave * NT * 16 + lane * 8 + i) * 2 + 1] = s2[i];
-        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // phase 1 overwrites what other lanes of this wave just read
+        __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
     const int t = threadIdx.x;
@@ -308,7 +316,8 @@ __global__ __launch_bounds__(256, 4) void conv_gather_kernel(ConvArgs a) {
     } else {
         conv_epilogue<NT>(a, acc, epi + wave * EROWS * EpiLds<NT>::LDW, n_base, pix, s1, s2);
     }
-    if (a.stats != nullptr) stats_flush<NT>(a, s1, s2, n_base, red, blockIdx.x);
+    static_assert(4 * EROWS * EpiLds<NT>::LDW >= 4 * STATS_SX_FLOATS, "epilogue buffer doubles as the statistics scratch");
+    if (a.stats != nullptr) stats_flush<NT>(a, s1, s2, n_base, red, epi, blockIdx.x);      // (conv_epilogue ends with a barrier)
 }
 
 template <int TAPS, bool AFF, bool RELU, int RS>
@@ -610,7 +619,10 @@ __global__ __launch_bounds__(256, ((CIN >= 64 && PF == 0) ? 2 : (CIN == 16 ? 4 :
             conv_epilogue<NT>(a, sub, epi, n_base, pix, s1, s2);
         }
     }
-    if (a.stats != nullptr) stats_flush<NT>(a, s1, s2, n_base, red, bid);
+    if (a.stats != nullptr) {
+        __syncthreads();      // the halo / epilogue region is free: it serves as the 16 KiB scratch of the statistics fold
+        stats_flush<NT>(a, s1, s2, n_base, red, (float*)smem, bid);
+    }
 }
 
 template <bool AFF, bool RELU, int RS>
@@ -626,6 +638,7 @@ static int launch_halo_nt(const ConvArgs& a, hipStream_t st) {
         size_t lds = halo;                                                                                   \
         const size_t epi = (size_t)4 * EpiLds<NTV>::FLOATS * 4;                                              \
         if (epi > lds) lds = epi;                                                                            \
+        if (lds < 4 * STATS_SX_FLOATS * 4) lds = 4 * STATS_SX_FLOATS * 4;                                    \
         int tp = (PFV) > 0 ? tpb : 1;                                                                        \
         if ((PFV) > 0 && (CINV) >= 64) { tp = (ntiles + 255) / 256; if (tp > 8) tp = 8; }   /* one persistent block per CU */ \
         if ((PFV) > 0) lds += (size_t)NTV * 16 * (a.Kpad * 2 + 16);                                          \
