@@ -79,6 +79,7 @@ __device__ __forceinline__ bf16x8 gather8(const SrcDesc& s, int H, int W, int n,
     const int sh_ = (RS == 1) ? (hh >> 1) : hh, sw_ = (RS == 1) ? (ww >> 1) : ww;
     const bf16x8 raw = *(const bf16x8*)((const bf16*)s.x + (((long)n * s.Hs + sh_) * s.Ws + sw_) * s.Cx + c);
     if (!AFF && !RELU) return raw;
+    if (!AFF && RELU) return relu8(raw);
     float v[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = bf2f(raw[i]);
@@ -438,7 +439,9 @@ __global__ __launch_bounds__(256, ((CIN >= 64 && PF == 0) ? 2 : (CIN == 16 ? 4 :
             const int hp = idx / chunks, cc = idx - hp * chunks;
             bf16x8 o = zero8();
             if (okmask & (1u << j)) {
-                if (AFF || RELU) {
+                if (!AFF && RELU) {
+                    o = relu8(raw[j]);
+                } else if (AFF || RELU) {
                     float v[8];
 #pragma unroll
                     for (int i = 0; i < 8; ++i) v[i] = bf2f(raw[j][i]);
@@ -502,7 +505,9 @@ __global__ __launch_bounds__(256, ((CIN >= 64 && PF == 0) ? 2 : (CIN == 16 ? 4 :
                     const int hp = idx / CH, cc = idx - hp * CH;
                     bf16x8 o = zero8();
                     if (okb & (1u << j)) {
-                        if (AFF || RELU) {
+                        if (!AFF && RELU) {
+                            o = relu8(rawb[j]);
+                        } else if (AFF || RELU) {
                             float v[8];
 #pragma unroll
                             for (int i = 0; i < 8; ++i) v[i] = bf2f(rawb[j][i]);
