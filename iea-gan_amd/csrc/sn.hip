@@ -158,8 +158,8 @@ __global__ __launch_bounds__(256) void sn_phase3_kernel(const long* __restrict__
             }
             p1[(long)o * kpad + k] = f2bf(v);
         }
-        for (long e = threadIdx.x; e < (long)rows * in; e += 256) {         // dgrad pack
-            const int o = row0 + (int)(e / in), i = (int)(e % in);
+        for (long e = threadIdx.x; e < (long)rows * in; e += 256) {         // dgrad pack: o fastest -> the 2-byte stores of
+            const int o = row0 + (int)(e % rows), i = (int)(e / rows);      // a wave are contiguous runs (the reads hit in cache)
             const int ci = i / taps, tap = i - ci * taps;
             p2[(long)ci * kpad2 + (taps - 1 - tap) * out + o] = f2bf(W[(long)o * in + i] * isg);
         }
