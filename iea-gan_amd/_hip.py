@@ -42,6 +42,7 @@ class ProfRec(C.Structure):
                 ("flops", C.c_double), ("bytes", C.c_double)]
 
 
+ABI_VERSION = 2            # include/ieagan_hip.h: IEAGAN_ABI_VERSION
 i, f, l = C.c_int, C.c_float, C.c_long
 _SIGS = {
     "ieagan_abi_version": [],
@@ -101,6 +102,10 @@ def lib():
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(iea-gan_amd/csrc/build.sh).  There is no PyTorch/CPU fallback for the MI355X path.")
         _lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        _lib.ieagan_abi_version.restype = C.c_int
+        if _lib.ieagan_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} has ABI version {_lib.ieagan_abi_version()}, the Python binding expects {ABI_VERSION}: "
+                               "rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
         _lib.ieagan_last_error.restype = C.c_char_p
         for name, sig in _SIGS.items():
             fn = getattr(_lib, name)

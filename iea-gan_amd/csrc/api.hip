@@ -21,7 +21,7 @@ void ieagan_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* ieagan_last_error(void) { return g_err; }
-extern "C" int ieagan_abi_version(void) { return 1; }
+extern "C" int ieagan_abi_version(void) { return IEAGAN_ABI_VERSION; }
 
 // ------------------------------------------------------------------------------------------------
 // profiling: when enabled every launcher brackets its launches with two events on its stream

@@ -19,7 +19,8 @@ extern "C" {
 #endif
 
 const char* ieagan_last_error(void);
-int ieagan_abi_version(void);
+#define IEAGAN_ABI_VERSION 2        /* bumped whenever a struct layout or a signature in this header changes */
+int ieagan_abi_version(void);        /* == IEAGAN_ABI_VERSION of the header the library was built from */
 
 /* ---- profiling hooks (bench.py): per-kernel HIP-event timing on the launch stream ---- */
 int ieagan_prof_enable(int on);          /* 0 off | 1 time every launch (hipEvents) | 2 + shape tags */
