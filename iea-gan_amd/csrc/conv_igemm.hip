@@ -117,7 +117,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x4 (&a
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) wlds[(mt * 16 + lg * 4 + r) * LDW + nt * 16 + lr] = acc[mt][nt][r];
-    __syncthreads();
+    // the transpose buffer is private to this wave: its LDS operations complete in order, the fence only pins the compiler
+    // (a block-wide barrier here made every wave wait for the slowest one four times per tile)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     const int cc = lane % CPP;
     const int co0 = n_base + cc * 8;
     const bool ch_ok = co0 < a.Cout;
@@ -175,7 +178,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x4 (&a
         }
         *(bf16x8*)((bf16*)a.out + m * a.Cout + co0) = o;
     }
-    __syncthreads();      // buffer may be reused (second half of a halo tile / next phase)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // the caller may overwrite the buffer (next half / next phase);
+    __builtin_amdgcn_wave_barrier();                             // anything that touches ANOTHER wave's region needs a block barrier
 }
 
 // fold the per-lane statistics partials (lane owns channel chunk lane % (2*NT)) and add them to the
@@ -318,7 +322,10 @@ __global__ __launch_bounds__(256, 4) void conv_gather_kernel(ConvArgs a) {
         conv_epilogue<NT>(a, acc, epi + wave * EROWS * EpiLds<NT>::LDW, n_base, pix, s1, s2);
     }
     static_assert(4 * EROWS * EpiLds<NT>::LDW >= 4 * STATS_SX_FLOATS, "epilogue buffer doubles as the statistics scratch");
-    if (a.stats != nullptr) stats_flush<NT>(a, s1, s2, n_base, red, epi, blockIdx.x);      // (conv_epilogue ends with a barrier)
+    if (a.stats != nullptr) {
+        __syncthreads();          // every wave is done with its part of the epilogue buffer, which now serves as fold scratch
+        stats_flush<NT>(a, s1, s2, n_base, red, epi, blockIdx.x);
+    }
 }
 
 template <int TAPS, bool AFF, bool RELU, int RS>
@@ -623,11 +630,9 @@ __global__ __launch_bounds__(256, ((CIN >= 64 && PF == 0) ? 2 : (CIN == 16 ? 4 :
             const f32x4(&sub)[2][NT] = *reinterpret_cast<const f32x4(*)[2][NT]>(&acc[2 * half]);
             conv_epilogue<NT>(a, sub, epi, n_base, pix, s1, s2);
         }
+        __syncthreads();      // every wave has left its epilogue buffer: the region is the next tile's halo / the fold scratch
     }
-    if (a.stats != nullptr) {
-        __syncthreads();      // the halo / epilogue region is free: it serves as the 16 KiB scratch of the statistics fold
-        stats_flush<NT>(a, s1, s2, n_base, red, (float*)smem, bid);
-    }
+    if (a.stats != nullptr) stats_flush<NT>(a, s1, s2, n_base, red, (float*)smem, bid);
 }
 
 template <bool AFF, bool RELU, int RS>
