@@ -63,26 +63,73 @@ class FusedAdam(torch.optim.Optimizer):
                 if g is not None:
                     p.grad.copy_(g)
         n = a.n_param
-        if self._m is None or self._m.numel() != n or self._m.device != a.flat.device:
+        if self._m is None:
             self._m = torch.zeros(n, dtype=torch.float32, device=a.flat.device)
             self._v = torch.zeros(n, dtype=torch.float32, device=a.flat.device)
+        elif self._m.numel() != n:
+            raise RuntimeError(f"FusedAdam: optimizer state holds {self._m.numel()} elements, the network's arena {n}")
+        elif self._m.device != a.flat.device:       # network moved after the state was created / loaded: follow it
+            self._m, self._v, self._hp = self._m.to(a.flat.device), self._v.to(a.flat.device), None
+            self.push_hyper()
         if not torch.cuda.is_current_stream_capturing():
             self.push_hyper()
         self._step += 1          # host mirror (informational; the device counter hp[4] is authoritative)
         H.call("ieagan_adam_step", a.flat.data_ptr(), a.grad.data_ptr(), self._m.data_ptr(), self._v.data_ptr(), n,
                self._hp.data_ptr(), H.stream())
 
-    # checkpoint format: flat moments + step (the reference's per-parameter dict does not survive the
-    # arena layout; utils.load_weights accepts both)
+    # Checkpoint format = torch.optim.Adam's own state dict ({'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}},
+    # 'param_groups': [...]}, parameters indexed in ``parameters()`` order, which equals the reference's order -- see
+    # tests/golden/state_dict_contract.json): the reference loads our G_optim.pth / D_optim.pth and we load its files.
+    # The flat moment buffers are split into per-parameter HOST copies on save and gathered back on load.
     def state_dict(self):
-        step = int(self._hp[4].item()) if self._hp is not None else self._step
-        return {"fused": True, "step": step, "exp_avg": self._m, "exp_avg_sq": self._v,
-                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+        a = self._arena() if (self.owner is not None and self._m is not None) else None
+        step = float(self._hp[4].item()) if self._hp is not None else float(self._step)
+        state = {}
+        if a is not None:
+            for i, (p, o, n) in enumerate(a.param_slices):
+                state[i] = {"step": torch.tensor(step), "exp_avg": self._m[o:o + n].view(p.shape).detach().cpu().clone(),
+                            "exp_avg_sq": self._v[o:o + n].view(p.shape).detach().cpu().clone()}
+        groups, k = [], 0
+        for g in self.param_groups:
+            d = {key: v for key, v in g.items() if key != "params"}
+            d["params"] = list(range(k, k + len(g["params"])))
+            k += len(g["params"])
+            groups.append(d)
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
-        if not sd.get("fused"):
-            raise ValueError("FusedAdam.load_state_dict expects a FusedAdam checkpoint")
-        self._step, self._m, self._v = sd["step"], sd["exp_avg"], sd["exp_avg_sq"]
-        self._hp = None
+        if sd.get("fused"):         # round-1 files: flat moments
+            flat_m, flat_v, step = sd["exp_avg"], sd["exp_avg_sq"], float(sd["step"])
+            per_param = None
+        else:
+            per_param, flat_m, flat_v = sd["state"], None, None
+            step = max([float(torch.as_tensor(s["step"]).item()) for s in per_param.values()] or [0.0])
         for g, s in zip(self.param_groups, sd["param_groups"]):
-            g.update(s)
+            g.update({k: v for k, v in s.items() if k != "params"})
+        self._step, self._hp = int(step), None
+        self._gather_moments(per_param, flat_m, flat_v)
+
+    def _gather_moments(self, per_param, flat_m, flat_v):
+        """Moments onto the arena's device, in arena order; a size mismatch raises (it must never silently re-zero:
+        that desynchronises data-parallel replicas on resume)."""
+        a = self._arena()
+        dev, n = a.flat.device, a.n_param
+        m = torch.zeros(n, dtype=torch.float32, device=dev)
+        v = torch.zeros(n, dtype=torch.float32, device=dev)
+        if per_param is None:
+            if flat_m.numel() != n or flat_v.numel() != n:
+                raise ValueError(f"optimizer checkpoint holds {flat_m.numel()} moment elements, the network has {n}")
+            m.copy_(flat_m.to(dev))
+            v.copy_(flat_v.to(dev))
+        else:
+            if per_param and len(per_param) != len(a.param_slices):
+                raise ValueError(f"optimizer checkpoint holds {len(per_param)} parameters, the network has {len(a.param_slices)}")
+            for i, (p, o, cnt) in enumerate(a.param_slices):
+                s = per_param.get(i)
+                if s is None:
+                    continue
+                if s["exp_avg"].numel() != cnt:
+                    raise ValueError(f"optimizer checkpoint: parameter {i} has {s['exp_avg'].numel()} elements, expected {cnt}")
+                m[o:o + cnt].copy_(s["exp_avg"].reshape(-1).to(dev, torch.float32))
+                v[o:o + cnt].copy_(s["exp_avg_sq"].reshape(-1).to(dev, torch.float32))
+        self._m, self._v = m, v

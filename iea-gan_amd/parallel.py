@@ -84,6 +84,30 @@ def shard_events(n_events: int, rank: int, world: int):
     return range(start, start + base + (1 if rank < rem else 0))
 
 
+def steps_per_rank(n_events: int, world: int) -> int:
+    """Iterations per epoch EVERY rank runs: one collective sequence per iteration, so the count must not depend on
+    the rank (the ``n_events % world`` tail is dropped).  0 means the run cannot start."""
+    return n_events // max(world, 1)
+
+
+def quiesce():
+    """Join the side stream (pending gradient exchanges + updates) and drain the device: call before reading network
+    state on the host (checkpoints)."""
+    if _CTX is not None:
+        _CTX.wait_all()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
+def shutdown():
+    """Leave the process group together: a rank that exits while another still sits in a collective would hang it."""
+    if _CTX is not None and torch.cuda.is_available():
+        _CTX.wait_all()
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def init_from_env(backend=None):
     """Initialise torch.distributed from the torchrun environment (RANK / WORLD_SIZE / MASTER_*)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))

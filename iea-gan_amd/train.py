@@ -4,14 +4,16 @@
 Keeps the reference's control flow (reference ``train.py``: run 22-247, main 250-259, epoch loop 158-173):
 defaults <- ``config.json`` (optional) <- command line, build G / D / G_ema / G_D, ``utils.prepare_z_y``,
 ``train_fns.GAN_training_function``, then per iteration ``G.train(); D.train(); metrics = train(x, y)``,
-metric / singular-value logging and periodic checkpoints in the reference's file layout.
+metric / singular-value logging and periodic checkpoints in the reference's file layout
+(``<outputroot>/<run_name>/{weights,logs,samples}``).
 
 Data: ``--dataroot DIR`` with one ``*.npy`` per event (uint8 ``[40, 250, 768]`` detector images, or float32
 already in [-1, 1]); the pad(3 rows) -> lognorm255 -> +4e-3 U dequantisation -> [-1, 1] chain of the
 reference's loader (utils/dataloader.py:59-76, utils/norm.py:8-19) runs on the GPU.  ``--synthetic N`` trains on
 N generated events (no files).  Any default of ``defaults.default_config()`` can be overridden as ``--key value``.
 Multi-GPU: launch with ``python -m torch.distributed.run --nproc-per-node N train.py ...`` (events are sharded
-over the ranks, gradients all-reduced over RCCL).
+over the ranks -- every rank takes ``len(events) // N`` per epoch, so all ranks issue the same collectives --
+gradients all-reduced over RCCL).
 """
 from __future__ import annotations
 
@@ -62,6 +64,7 @@ def parse(argv):
             cfg[key] = None if val.lower() in ("none", "null") else (type(cur)(val) if cur is not None else json.loads(val))
     cfg.update(device=args.device, dataroot=args.dataroot, outputroot=args.outputroot, synthetic=args.synthetic,
                max_iters=args.max_iters)
+    cfg.setdefault("load_weights", "")
     return cfg
 
 
@@ -96,19 +99,26 @@ def run(cfg):
         G_ema = model.Generator(**dict(cfg, skip_init=True, no_optim=True)).to(dev)
         ema = utils.apply_ema(G, G_ema, cfg["ema_decay"], cfg["ema_start"])
     GD = model.G_D(G, D)
-    state = {"itr": 0, "epoch": 0, "save_num": 0, "best_FID": 999999, "config": cfg}
+    state = {"itr": 0, "epoch": 0, "save_num": 0, "save_best_num": 0, "best_FID": 999999}
     name = cfg["run_name"]
-    wroot, lroot = os.path.join(cfg["outputroot"], "weights"), os.path.join(cfg["outputroot"], "logs")
+    run_dir = os.path.join(cfg["outputroot"], name)          # reference layout: <outputroot>/<run_name>/{weights,logs,samples}
+    lroot = os.path.join(run_dir, "logs")
+    if rank == 0:
+        for sub in ("weights", "logs", "samples"):
+            os.makedirs(os.path.join(run_dir, sub), exist_ok=True)
     if cfg["resume"]:
-        utils.load_weights(G, D, state, wroot, name, None, G_ema, load_optim=cfg["load_optim"])
+        utils.load_weights(G, D, state, cfg, cfg.get("load_weights") or None, G_ema, load_optim=cfg["load_optim"])
     if world > 1:
+        # every replica starts from rank 0's state: G, D and the EMA copy (one flat arena each -> one broadcast each)
         for net in (G, D):
             net._prepare()
             parallel.broadcast_flat(net._arena.flat)
+        if G_ema is not None:
+            parallel.broadcast_flat(ema._arenas()[1].flat)
     utils.count_parameters(G)
     utils.count_parameters(D)
     if rank == 0:
-        utils.write_metadata(lroot, name, {k: v for k, v in cfg.items()}, {k: v for k, v in state.items() if k != "config"})
+        utils.write_metadata(cfg, state)
     h, w = cfg["resolution"], cfg["resolution"] * cfg["H_base"]
     if cfg["synthetic"]:
         events = [synthetic_event(cfg["n_classes"], h - 6, w, cfg["seed"] + i) for i in range(cfg["synthetic"])]
@@ -117,13 +127,26 @@ def run(cfg):
         if not files:
             raise SystemExit("no *.npy events under --dataroot (or use --synthetic N)")
         events = files
-    mine = [events[i] for i in parallel.shard_events(len(events), rank, world)]
+    # Every rank must issue the same number of collectives: each takes exactly len(events) // world events per epoch
+    # (the remainder is dropped, like DataLoader(drop_last=True)); fewer events than ranks is an error raised before
+    # any collective is issued.
+    per_rank = parallel.steps_per_rank(len(events), world)
+    if per_rank == 0:
+        raise SystemExit(f"{len(events)} event(s) cannot be sharded over {world} ranks (need at least one per rank)")
+    mine = [events[i] for i in parallel.shard_events(len(events), rank, world)][:per_rank]
     z_, y_ = utils.prepare_z_y(max(cfg["G_batch_size"], cfg["batch_size"]), G.dim_z, cfg["n_classes"], device=dev,
                                z_dist=cfg["z_dist"], threshold=cfg["truncated_threshold"])
     train = train_fns.GAN_training_function(G, D, GD, z_, y_, ema, state, cfg, dev)
     y = torch.arange(cfg["n_classes"], device=dev)
-    log = open(os.path.join(lroot, name, f"metrics_rank{rank}.jsonl"), "a") if rank == 0 else None
+    log = open(os.path.join(lroot, f"metrics_rank{rank}.jsonl"), "a") if rank == 0 else None
     t0 = time.time()
+
+    def checkpoint():
+        parallel.quiesce()              # side-stream updates have landed before the arenas are copied to the host
+        if rank == 0:
+            utils.save_weights(G, D, state, cfg, None, G_ema)
+
+    stop = False
     for epoch in range(state["epoch"], cfg["num_epochs"]):
         order = np.random.permutation(len(mine)) if cfg["shuffle"] else np.arange(len(mine))
         for i in order:
@@ -137,7 +160,7 @@ def run(cfg):
             metrics = train(x, y)
             if log is not None:
                 rec = dict(itr=state["itr"], **metrics)
-                if state["itr"] % cfg["sv_log_interval"] == 0:
+                if cfg["sv_log_interval"] > 0 and state["itr"] % cfg["sv_log_interval"] == 0:
                     rec.update(utils.get_singular_values(G, "G"))
                     rec.update(utils.get_singular_values(D, "D"))
                 log.write(json.dumps(rec) + "\n")
@@ -145,16 +168,21 @@ def run(cfg):
             if state["itr"] % cfg["log_interval"] == 0 and rank == 0:
                 print(f"itr {state['itr']}  {(time.time() - t0) / state['itr']:.3f} s/itr  " +
                       "  ".join(f"{k} {v:.4f}" for k, v in metrics.items()))
-            if state["itr"] % cfg["save_every"] == 0 and rank == 0:
-                utils.save_weights(G, D, {k: v for k, v in state.items() if k != "config"}, wroot, name, None, G_ema)
+            if state["itr"] % cfg["save_every"] == 0:
+                checkpoint()
             if cfg["max_iters"] and state["itr"] >= cfg["max_iters"]:
+                stop = True
                 break
         state["epoch"] += 1
-        if cfg["max_iters"] and state["itr"] >= cfg["max_iters"]:
+        for net in (G, D):
+            if net.lr_sched is not None:
+                net.lr_sched.step()
+        if stop:
             break
+    checkpoint()
     if rank == 0:
-        utils.save_weights(G, D, {k: v for k, v in state.items() if k != "config"}, wroot, name, None, G_ema)
-        print(f"done: {state['itr']} iterations, weights under {os.path.join(wroot, name)}")
+        print(f"done: {state['itr']} iterations, weights under {os.path.join(run_dir, 'weights')}")
+    parallel.shutdown()                 # barrier + destroy_process_group: no rank leaves while another is in a collective
     return state
 
 

@@ -67,6 +67,33 @@ class _Replay:
         self.graph.replay()
         return self.out
 
+    def reset(self):
+        """Forget the captured graph (its static inputs were re-allocated): warm up and capture again."""
+        self.calls, self.graph, self.out = 0, None, None
+
+
+def test(G, D, G_ema, state_dict, config, test_log):
+    """FID bookkeeping of the reference (train_fns.py:209-233): the metric itself needs the PXD Inception network of
+    ``mycleanfid`` (weights not distributed with the reference) and is outside the accelerated path.  When
+    a reference checkout with ``mycleanfid`` is importable the reference's call is made with this package's generator;
+    otherwise the iteration is logged without a score instead of aborting the training run."""
+    try:
+        from mycleanfid import fid
+    except Exception as e:            # cleanfid / cv2 / the Inception blob are missing
+        print(f"FID skipped at itr {state_dict['itr']}: mycleanfid is not importable ({type(e).__name__}: {e})")
+        test_log.log(itr=int(state_dict["itr"]), FID=None)
+        return
+    print("Gathering inception metrics...")
+    FID = fid.compute_fid(gen=G, dataset_name="pxd_sim_test_com", dataset_res=256, batch_size=40, mode="clean",
+                          dataset_split="custom", z_dim=128, num_gen=config["num_incep_images"], trunc=None,
+                          device=config["device"])
+    print(f"The FID score is {FID}")
+    if config["which_best"] == "FID" and FID < state_dict["best_FID"]:
+        print("%s improved over previous best, saving checkpoint..." % config["which_best"])
+        state_dict["save_best_num"] = (state_dict["save_best_num"] + 1) % config["num_best_copies"]
+    state_dict["best_FID"] = min(state_dict["best_FID"], FID)
+    test_log.log(itr=int(state_dict["itr"]), FID=float(FID))
+
 
 def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
     if config["pos_collected_numerator"]:
@@ -206,24 +233,30 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
         return torch.zeros((), device=st["y"].device)
 
     def reduce(net, key, then=None):
-        """Data parallel: average the flat gradient arena over the ranks; ``then`` runs behind it (D: side stream)."""
+        """Data parallel: average the flat gradient arena over the ranks on the side stream, ``then`` (the update) behind
+        it.  D's exchange + Adam overlap the G-phase generator forward; G's exchange + ortho + Adam + EMA overlap whatever
+        the main stream and the host do until the generator is evaluated again (ingestion of the next event, loss
+        read-back, logging) -- the main stream re-joins in ``sync.wait`` at the top of the next step."""
         if sync is not None:
-            sync.reduce_then(key, net._arena.grad, then, blocking=(key == "G"))
+            sync.reduce_then(key, net._arena.grad, then)
         elif then is not None:
             then()
 
     def step_tensor(run_d, run_g, run_gu, replayed=False):
         """[G_loss, D_loss_real, D_loss_fake, unif_loss_d, iea_loss] as one device tensor (no host sync)."""
         for _ in range(config["num_D_steps"]):
-            if replayed and sync is not None:
-                sync.wait("D")          # a replayed graph runs no Python hooks: order it behind D's update explicitly
+            if sync is not None:
+                # D's previous all-reduce + Adam (side stream) still read the gradient arena that this iteration zeroes
+                # first thing: order the main stream behind them here (eager: the forward pre-hook fires too late for
+                # zero_grad(); replayed: a graph runs no Python hooks at all)
+                sync.wait("D")
+                sync.wait("G")          # likewise G's update of the previous step (it zeroes / reads G's gradient arena)
             dv = run_d()
             reduce(D, "D", d_update)
         if replayed and sync is not None:
             sync.wait("D")
         gv = run_g()
-        reduce(G, "G")          # the ortho term is deterministic in W: added after the gradient mean
-        run_gu()
+        reduce(G, "G", run_gu)  # the ortho term is deterministic in W: added after the gradient mean
         return torch.stack([gv[0], dv[0], dv[1], dv[2], gv[1]])
 
     def whole_step():
@@ -246,8 +279,10 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
             vals = whole_step()
             st["noise"] = None
             return dict(zip(KEYS, vals.tolist()))
-        if st.get("static") is None or st["x"].shape != x.shape:
+        if st.get("static") is None or st["x"].shape != x.shape or st["y"].shape != y.shape:
             st["x"], st["y"], st["static"] = x.clone(), y.clone(), True     # static inputs of the captured graphs
+            for r in (whole, *seg):     # graphs captured against the previous static buffers / shapes are stale
+                r.reset()
         st["x"].copy_(x)
         st["y"].copy_(y)
         st["noise"] = None

@@ -1,14 +1,36 @@
 """Train-step utilities behind the reference's ``utils`` surface (reference ``utils/__init__.py``:
 Distribution 41-120, prepare_z_y 124-158, seed_rng 218-226, toggle_grad 261-263, make_mask 266-275,
 apply_ema 809-837, ortho 843-859).  Host-side bookkeeping of the reference (sample sheets, plots,
-Inception statistics) is out of scope of the MI355X hot path.
+Inception statistics) is out of scope of the MI355X hot path.  Checkpoint I/O, metadata and singular-value
+logging keep the reference's signatures and on-disk layout (load_weights 592, write_metadata 671, save_weights 689,
+save_and_sample 299, get_singular_values 572).
 """
 from __future__ import annotations
+
+import os as _os
+import sys as _sys
 
 import numpy as np
 import torch
 
 import _hip as H
+
+
+def _fall_through_to_reference_checkout():
+    """The reference's scripts also import the host-side bookkeeping sub-modules ``utils.configuration``,
+    ``utils.logging``, ``utils.dataloader``, ``utils.plot``, ``utils.norm`` and ``utils.noise`` (reference
+    train.py:16-19, utils/__init__.py:30).  They are outside the accelerated path and are not re-implemented here:
+    when a reference checkout is on ``sys.path`` behind this package (``dropin.py``), its
+    ``utils/`` directory is appended to this package's search path so those sub-modules resolve to the user's own
+    files, while every name defined in this file keeps shadowing the reference's ``utils/__init__.py``."""
+    here = _os.path.dirname(_os.path.abspath(__file__))
+    for p in list(_sys.path):
+        cand = _os.path.join(_os.path.abspath(p or "."), "utils")
+        if cand != here and cand not in __path__ and _os.path.isfile(_os.path.join(cand, "configuration.py")):
+            __path__.append(cand)
+
+
+_fall_through_to_reference_checkout()
 
 
 class Distribution(torch.Tensor):
@@ -237,75 +259,125 @@ def count_parameters(module):
 
 
 # ---------------------------------------------------------------------------------------------------------
-# checkpoint I/O and singular-value logging: the reference's file layout
-# {G, G_optim, D, D_optim, state_dict, G_ema}[_suffix].pth (utils/__init__.py:689-726, 592-668)
+# checkpoint I/O, metadata and singular-value logging with the reference's signatures, file layout and key format
+# (utils/__init__.py: join_strings 229, rename_weight_keys 242, save_and_sample 299, get_singular_values 572,
+#  load_weights 592, write_metadata 671, save_weights 689): <outputroot>/<run_name>/{weights,logs,samples}/...
 # ---------------------------------------------------------------------------------------------------------
-def _ckpt_name(root, experiment_name, stem, suffix):
-    import os
-    return os.path.join(root, experiment_name, f"{stem}_{suffix}.pth" if suffix else f"{stem}.pth")
+def join_strings(delimiter, strings):
+    return delimiter.join([s for s in strings if s])
 
 
-def save_weights(G, D, state_dict, weights_root, experiment_name, name_suffix=None, G_ema=None):
-    import os
-    os.makedirs(os.path.join(weights_root, experiment_name), exist_ok=True)
-    clone = lambda sd: {k: v.detach().clone().cpu() for k, v in sd.items()}     # detach the views from the flat arena
-    torch.save(clone(G.state_dict()), _ckpt_name(weights_root, experiment_name, "G", name_suffix))
-    torch.save(G.optim.state_dict(), _ckpt_name(weights_root, experiment_name, "G_optim", name_suffix))
-    torch.save(clone(D.state_dict()), _ckpt_name(weights_root, experiment_name, "D", name_suffix))
-    torch.save(D.optim.state_dict(), _ckpt_name(weights_root, experiment_name, "D_optim", name_suffix))
-    torch.save(state_dict, _ckpt_name(weights_root, experiment_name, "state_dict", name_suffix))
+def rename_weight_keys(state_dict, fragment, replacement):
+    from collections import OrderedDict
+    return OrderedDict((k.replace(fragment, replacement) if isinstance(k, str) else k, v) for k, v in state_dict.items())
+
+
+def _run_dir(configuration, sub):
+    import pathlib
+    return pathlib.Path(configuration["outputroot"]).joinpath(configuration["run_name"]).joinpath(sub)
+
+
+def _host_copy(sd):
+    """State-dict entries are views of the network's flat arena: store detached host copies."""
+    return type(sd)((k, v.detach().cpu().clone()) for k, v in sd.items())
+
+
+def save_weights(G, D, state_dict, configuration, name_suffix=None, G_ema=None):
+    """{G, G_optim, D, D_optim, state_dict, G_ema}[_suffix].pth under <outputroot>/<run_name>/weights; the optimizer
+    files are in torch.optim.Adam's own state-dict format (``FusedAdam.state_dict``), so either implementation loads
+    the other's checkpoint."""
+    wdir = _run_dir(configuration, "weights")
+    wdir.mkdir(parents=True, exist_ok=True)
+    print("Saving weights to %s%s..." % (wdir.absolute(), "/" + name_suffix if name_suffix else ""))
+    path = lambda stem: "%s/%s.pth" % (wdir.absolute(), join_strings("_", [stem, name_suffix]))
+    torch.save(_host_copy(G.state_dict()), path("G"))
+    torch.save(G.optim.state_dict(), path("G_optim"))
+    torch.save(_host_copy(D.state_dict()), path("D"))
+    torch.save(D.optim.state_dict(), path("D_optim"))
+    torch.save({k: v for k, v in state_dict.items() if k != "config"}, path("state_dict"))
     if G_ema is not None:
-        torch.save(clone(G_ema.state_dict()), _ckpt_name(weights_root, experiment_name, "G_ema", name_suffix))
+        torch.save(_host_copy(G_ema.state_dict()), path("G_ema"))
 
 
-def _rename_legacy(sd):
-    """Checkpoints of older reference revisions call the RRMs ``transG`` / ``transcoder`` (utils/__init__.py:242-258)."""
-    return {k.replace("transG", "RR_G").replace("transcoder", "RR_D"): v for k, v in sd.items()}
+def load_weights(G, D, state_dict, configuration, weight_name=None, G_ema=None, strict=True, load_optim=True):
+    wdir = _run_dir(configuration, "weights")
+    print(f"Loading {weight_name + ' ' if weight_name else ''}weights from {wdir.absolute()}...")
+    path = lambda stem: wdir.joinpath(f"{join_strings('_', [stem, weight_name])}.pth").absolute()
+    # always to the host first: the tensors are copied into the (already placed) flat arenas, and a data-parallel
+    # rank must not create a context on GPU 0 by unpickling another rank's CUDA tensors
+    read = lambda stem: torch.load(path(stem), map_location="cpu")
 
-
-def load_weights(G, D, state_dict, weights_root, experiment_name, name_suffix=None, G_ema=None, strict=True, load_optim=True):
-    def load(net, stem):
-        sd = torch.load(_ckpt_name(weights_root, experiment_name, stem, name_suffix), map_location="cpu")
+    def load_net(net, stem, old, new):
+        sd = read(stem)
         try:
             net.load_state_dict(sd, strict=strict)
         except RuntimeError:
-            net.load_state_dict(_rename_legacy(sd), strict=strict)
+            print("Mismatch between file weight keys and model keys. Try renaming.")
+            net.load_state_dict(rename_weight_keys(sd, old, new), strict=strict)
+
     if G is not None:
-        load(G, "G")
+        load_net(G, "G", "transG", "RR_G")
         if load_optim:
-            try:
-                G.optim.load_state_dict(torch.load(_ckpt_name(weights_root, experiment_name, "G_optim", name_suffix)))
-            except (ValueError, FileNotFoundError):
-                print("G optimizer state not loaded (a reference-format Adam checkpoint does not map onto the flat arena)")
+            G.optim.load_state_dict(read("G_optim"))
     if D is not None:
-        load(D, "D")
+        load_net(D, "D", "transcoder", "RR_D")
         if load_optim:
-            try:
-                D.optim.load_state_dict(torch.load(_ckpt_name(weights_root, experiment_name, "D_optim", name_suffix)))
-            except (ValueError, FileNotFoundError):
-                print("D optimizer state not loaded")
-    for k, v in torch.load(_ckpt_name(weights_root, experiment_name, "state_dict", name_suffix)).items():
-        state_dict[k] = v
+            D.optim.load_state_dict(read("D_optim"))
+    saved = read("state_dict")
+    for item in state_dict:
+        if item in saved:
+            state_dict[item] = saved[item]
     if G_ema is not None:
-        load(G_ema, "G_ema")
+        load_net(G_ema, "G_ema", "transG", "RR_G")
 
 
-def get_singular_values(net, prefix):
-    """{'<prefix>_<layer>_SV0': sigma} for every spectrally normalised layer, with ONE device-to-host copy
-    (the reference does one ``.item()`` per layer: ~211 host syncs every sv_log_interval iterations)."""
+def write_metadata(configuration, state_dict):
+    import datetime
+    ldir = _run_dir(configuration, "logs")
+    ldir.mkdir(parents=True, exist_ok=True)
+    with open(ldir.joinpath("metalog.txt").absolute(), "w") as f:
+        f.write("datetime: %s\n" % str(datetime.datetime.now()))
+        f.write("state: %s\n" % str(state_dict))
+
+
+def get_singular_values(module, prefix):
+    """{'<prefix>_<state-dict key with dots as underscores>': sigma} for every ``sv`` buffer (reference key format, e.g.
+    ``G_linear_sv0``), read back with ONE device-to-host copy -- the reference does one ``.item()`` per layer, ~211 host
+    synchronisations every sv_log_interval iterations."""
     names, vals = [], []
-    for k, v in net.state_dict().items():
-        if k.endswith(".sv0") or k == "sv0":
+    for k, v in module.state_dict().items():
+        if "sv" in k:
             names.append(k)
             vals.append(v.reshape(-1)[:1])
     if not names:
         return {}
     host = torch.cat(vals).float().cpu().tolist()
-    return {f"{prefix}_{n[:-4].replace('.', '_')}_SV0": float(x) for n, x in zip(names, host)}
+    return {f"{prefix}_{n}".replace(".", "_"): float(x) for n, x in zip(names, host)}
 
 
-def write_metadata(logs_root, experiment_name, config, state_dict):
-    import datetime, os
-    os.makedirs(os.path.join(logs_root, experiment_name), exist_ok=True)
-    with open(os.path.join(logs_root, experiment_name, "metalog.txt"), "w") as f:
-        f.write(f"datetime: {datetime.datetime.now()}\nconfig: {config}\nstate: {state_dict}\n")
+def denorm(x, crop=True):
+    """[-1, 1] network range -> detector units [0, 255] (+ the 3-row crop): reference utils/norm.py:34-46."""
+    x = torch.pow(256.0, x.float() * 0.5 + 0.5) - 1.0
+    x = x.clamp(0, 255)
+    return x[..., 3:-3, :] if crop else x
+
+
+def save_and_sample(G, D, G_ema, z_, y_, fixed_z, fixed_y, state_dict, config):
+    """Checkpoint copy + fixed-latent sample of the current generator (reference utils/__init__.py:299-365).  The
+    sample is written as ``samples/fixed_samples<itr>.npy`` (detector units, [N, 1, H-6, W]); the reference's JPEG
+    sheet additionally needs torchvision and is written only when that is importable."""
+    save_weights(G, D, state_dict, config, "copy%d" % state_dict["itr"], G_ema if config["ema"] else None)
+    if config["num_save_copies"] > 0:
+        state_dict["save_num"] = (state_dict["save_num"] + 1) % config["num_save_copies"]
+    which_G = G_ema if (config["ema"] and config["use_ema"]) else G
+    with torch.no_grad():
+        imgs = denorm(which_G(fixed_z, fixed_y).float()).cpu()
+    sdir = _run_dir(config, "samples")
+    sdir.mkdir(parents=True, exist_ok=True)
+    np.save(str(sdir.joinpath(f"fixed_samples{state_dict['itr']}.npy").absolute()), imgs.numpy())
+    try:
+        from torchvision.utils import save_image
+    except Exception:
+        return
+    save_image(imgs, sdir.joinpath(f"fixed_samples{state_dict['itr']}.jpg").absolute(), nrow=int(imgs.shape[0] ** 0.5),
+               normalize=False)

@@ -215,7 +215,8 @@ def test_hip_graph_replay_is_stable():
 
 def test_train_entry_point_and_checkpoint_round_trip(tmp_path):
     """train.py end to end on 3 synthetic events (64x64), then save_weights / load_weights in the reference's
-    file layout and the batched singular-value read-out."""
+    file layout (<outputroot>/<run_name>/weights), optimizer state in torch.optim.Adam's format, and the batched
+    singular-value read-out; resuming continues bit-identically to an uninterrupted run of the optimizer state."""
     import io, contextlib
     import model, train, utils
     cfg = train.parse(["--synthetic", "3", "--resolution", "64", "--H_base", "1", "--clip_norm", "1e9", "--max_iters", "3",
@@ -223,20 +224,40 @@ def test_train_entry_point_and_checkpoint_round_trip(tmp_path):
     with contextlib.redirect_stdout(io.StringIO()):
         state = train.run(cfg)
     assert state["itr"] == 3
-    wdir = os.path.join(str(tmp_path), "weights", cfg["run_name"])
+    wdir = os.path.join(str(tmp_path), cfg["run_name"], "weights")
     assert sorted(os.listdir(wdir)) == ["D.pth", "D_optim.pth", "G.pth", "G_ema.pth", "G_optim.pth", "state_dict.pth"]
-    lines = open(os.path.join(str(tmp_path), "logs", cfg["run_name"], "metrics_rank0.jsonl")).read().strip().splitlines()
+    lines = open(os.path.join(str(tmp_path), cfg["run_name"], "logs", "metrics_rank0.jsonl")).read().strip().splitlines()
     rec = json.loads(lines[-1])
-    assert {"G_loss", "D_loss_real", "D_loss_fake", "unif_loss_d", "iea_loss"} <= set(rec) and "G_linear_SV0" in rec
+    assert {"G_loss", "D_loss_real", "D_loss_fake", "unif_loss_d", "iea_loss"} <= set(rec) and "G_linear_sv0" in rec
     assert all(np.isfinite(v) for v in rec.values())
     with contextlib.redirect_stdout(io.StringIO()):
         G = model.Generator(**cfg).cuda()
         D = model.Discriminator(**cfg).cuda()
-    st = {}
-    utils.load_weights(G, D, st, os.path.join(str(tmp_path), "weights"), cfg["run_name"])
+    st = {"itr": 0, "epoch": 0}
+    with contextlib.redirect_stdout(io.StringIO()):
+        utils.load_weights(G, D, st, cfg, None, None, load_optim=True)
     ref = torch.load(os.path.join(wdir, "G.pth"))
     assert st["itr"] == 3 and all(torch.equal(G.state_dict()[k].cpu(), v) for k, v in ref.items())
-    assert int(G.optim.state_dict()["step"]) == 3
+    osd = torch.load(os.path.join(wdir, "G_optim.pth"))
+    assert set(osd) == {"state", "param_groups"} and float(osd["state"][0]["step"]) == 3.0
+    assert not osd["state"][0]["exp_avg"].is_cuda                       # host copies, never pinned to one rank's GPU
+    assert G.optim._m.is_cuda and G.optim._m.device == G._arena.flat.device
+    n0 = G._arena.param_slices[3][2]
+    o0 = G._arena.param_slices[3][1]
+    assert torch.equal(G.optim._v[o0:o0 + n0].cpu(), osd["state"][3]["exp_avg_sq"].reshape(-1))
+    # reference-format Adam state -> one more step == torch.optim.Adam's own step on the same gradient
+    gen = torch.Generator().manual_seed(3)
+    g = torch.randn(G._arena.n_param, generator=gen).cuda() * 1e-3
+    ref_opt = torch.optim.Adam([torch.nn.Parameter(G._arena.flat[:G._arena.n_param].clone())], lr=cfg["G_lr"],
+                               betas=(cfg["G_B1"], cfg["G_B2"]), eps=cfg["adam_eps"])
+    ref_opt.param_groups[0]["params"][0].grad = g.clone()
+    ref_opt.state[ref_opt.param_groups[0]["params"][0]] = {"step": torch.tensor(3.0), "exp_avg": G.optim._m.clone(),
+                                                           "exp_avg_sq": G.optim._v.clone()}
+    ref_opt.step()
+    G.optim.zero_grad()
+    G._arena.grad.copy_(g)
+    G.optim.step()
+    assert torch.allclose(G._arena.flat[:G._arena.n_param], ref_opt.param_groups[0]["params"][0].data, rtol=1e-5, atol=1e-7)
 
 
 @pytest.mark.parametrize("graph", [False, True])
