@@ -97,9 +97,23 @@ def _weight(sd, prefix, training, eps):
     return sn_weight(sd, prefix, training, eps) if _has_sn(sd, prefix) else sd[prefix + ".weight"]
 
 
+# Probe switch (tests only): emulate the HIP path's storage precision inside the fp32 restatement -- the conv
+# operands (activated input, normalised weight) and the conv output are rounded to bf16 with a straight-through
+# gradient.  Used to measure how far bf16 activation storage alone moves losses / gradients (the noise floor the
+# HIP-vs-oracle tolerances are stated against).  False = the reference's arithmetic.
+ROUND_BF16 = False
+
+
+def _r16(t: Tensor) -> Tensor:
+    return t + (t.to(torch.bfloat16).to(t.dtype) - t).detach()
+
+
 def conv(sd, prefix, x, training, eps, padding):
     """SNConv2d.forward (layers.py:197-206)."""
-    return F.conv2d(x, _weight(sd, prefix, training, eps), sd.get(prefix + ".bias"), 1, padding)
+    w = _weight(sd, prefix, training, eps)
+    if ROUND_BF16:
+        return _r16(F.conv2d(_r16(x), _r16(w), sd.get(prefix + ".bias"), 1, padding))
+    return F.conv2d(x, w, sd.get(prefix + ".bias"), 1, padding)
 
 
 def linear(sd, prefix, x, training, eps):
@@ -409,19 +423,27 @@ class TrainState:
         self.ema: Optional[State] = None
 
 
-def train_step(ts: TrainState, x: Tensor, y: Tensor, noise: dict, itr: int = 1) -> Dict[str, float]:
-    """One D update + one G update (train_fns.py:23-205, Contra branch, split_D, no Con_reg).
+def _buffers(sd: State) -> State:
+    return {k: v.detach().clone() for k, v in sd.items() if is_buffer(k)}
 
-    ``noise`` = {'z_d','rdof_d','aug_d' (dict|None), 'z_g','rdof_g','aug_g'}: the explicit draws of
-    the D-phase and G-phase generator passes.  Config keys used: contra_lambda, IEA_loss/IEA_lambda,
-    Uniformity_loss/unif_lambda, diff_aug, G_ortho, clip_norm, ema.  Terms switched off contribute
-    0.0 to the returned dict (the reference raises UnboundLocalError there).
-    ``clip_norm=None`` reproduces the reference quirk that G's optimiser never steps (9-Q1)."""
+
+def _restore(sd: State, snap: State) -> None:
+    with torch.no_grad():
+        for k, v in snap.items():
+            sd[k].copy_(v)
+
+
+def _mean_states(snaps) -> State:
+    return {k: torch.stack([s[k] for s in snaps]).mean(0) for k in snaps[0]}
+
+
+def _d_phase_loss(ts: TrainState, x: Tensor, y: Tensor, noise: dict):
+    """D-phase loss of ONE event (train_fns.py:49-130): generator under no_grad, D(fake) then D(real), hinge +
+    contrastive + uniformity; with ``Con_reg`` a third pass D(CR_DiffAug(x)) after the real one and
+    cr_lambda * (l2(D_real, D_real_aug) + l2(embed_real, embed_real_aug)) (train_fns.py:93-102; SURVEY 9-Q3: with
+    split_D the reference raises before it gets there, the third pass is the defined semantics)."""
     cfg, g, d = ts.cfg, ts.g, ts.d
     zero = torch.zeros(())
-    # ---------------- D phase (train_fns.py:41-139)
-    _set_requires_grad(d, ts.d_params, True)
-    _set_requires_grad(g, ts.g_params, False)
     with torch.no_grad():                                                          # model.py:973-978
         gz = generator(g, cfg, noise["z_d"], y, noise["rdof_d"], True)
         if cfg.get("diff_aug", True):
@@ -436,8 +458,68 @@ def train_step(ts: TrainState, x: Tensor, y: Tensor, noise: dict, itr: int = 1) 
     if cfg.get("Uniformity_loss", False):
         unif_d = unif_loss(emb_r)
         d_loss = d_loss + cfg["unif_lambda"] * unif_d
-    grads = torch.autograd.grad(d_loss, [d[k] for k in ts.d_params], allow_unused=True)
-    d_grads = {k: (gr if gr is not None else torch.zeros_like(d[k])) for k, gr in zip(ts.d_params, grads)}
+    if cfg.get("Con_reg", False):
+        x_aug = cr_diff_augment(x, noise["cr"])                                    # train_fns.py:27-28
+        _, emb_a, d_real_a = discriminator(d, cfg, x_aug, y, True)
+        d_loss = d_loss + cfg["cr_lambda"] * (l2_loss(d_real, d_real_a) + l2_loss(emb_r, emb_a))
+    return d_loss, (l_real, l_fake, unif_d), emb_r.detach()
+
+
+def _g_phase_loss(ts: TrainState, y: Tensor, noise: dict, emb_r: Tensor):
+    """G-phase loss of ONE event (train_fns.py:150-181)."""
+    cfg, g, d = ts.cfg, ts.g, ts.d
+    gz = generator(g, cfg, noise["z_g"], y, noise["rdof_g"], True)
+    if cfg.get("diff_aug", True):
+        gz = diff_augment(gz, noise["aug_g"])
+    proxy_f, emb_f, d_fake = discriminator(d, cfg, gz, y, True)
+    g_loss = hinge_gen(d_fake)
+    if cfg.get("contra_lambda", 1.0) != 0:
+        g_loss = g_loss + cfg["contra_lambda"] * contrastive_loss(emb_f, proxy_f)
+    iea = torch.zeros(())
+    if cfg.get("IEA_loss", False):
+        iea = iea_loss(emb_f, emb_r)
+        g_loss = g_loss + cfg["IEA_lambda"] * iea
+        if cfg.get("Uniformity_loss", False):                                      # nested, :171-178
+            g_loss = g_loss + cfg["unif_lambda"] * unif_loss(emb_f)
+    return g_loss, iea
+
+
+def train_step_events(ts: TrainState, xs, y: Tensor, noises, itr: int = 1) -> Dict[str, float]:
+    """One D update + one G update over E = len(xs) events per step (BASELINE configs[3]).
+
+    The reference consumes exactly one event per step, so E > 1 is DEFINED here as E-way data parallelism on one
+    device: every event is an independent pass from the SAME weights and the SAME buffers (per-event BatchNorm
+    statistics, RRM tokens and loss Grams; the spectral-norm power iteration advances once per pass -- it depends on
+    the weights only, so every event computes the identical ``u0`` / ``sv0``), the gradients are averaged over the
+    events, and the BatchNorm running statistics after a pass are the mean of the E per-event momentum updates
+    (not E sequential updates -- stated deviation, there is no reference behaviour to follow).  E = 1 is exactly
+    ``train_step``.  ``noises[e]`` holds the draws of event e (see ``train_step``; plus 'cr' with ``Con_reg``)."""
+    cfg, g, d = ts.cfg, ts.g, ts.d
+    E = len(xs)
+
+    def over_events(net_states, loss_fn, params_of):
+        """Run ``loss_fn(e)`` for every event from the same starting buffers; return mean grads / values."""
+        start = [_buffers(sd) for sd in net_states]
+        ends, grads, vals, extra = [], None, [], []
+        for e in range(E):
+            for sd, snap in zip(net_states, start):
+                _restore(sd, snap)
+            loss, v, ex = loss_fn(e)
+            gr = torch.autograd.grad(loss, [params_of[0][k] for k in params_of[1]], allow_unused=True)
+            gr = [(t if t is not None else torch.zeros_like(params_of[0][k])) for t, k in zip(gr, params_of[1])]
+            grads = gr if grads is None else [a + b for a, b in zip(grads, gr)]
+            vals.append([float(t) for t in v] + [float(loss)])
+            extra.append(ex)
+            ends.append([_buffers(sd) for sd in net_states])
+        for i, sd in enumerate(net_states):
+            _restore(sd, _mean_states([en[i] for en in ends]))
+        mean_vals = [sum(c) / E for c in zip(*vals)]
+        return {k: t / E for k, t in zip(params_of[1], grads)}, mean_vals, extra
+
+    # ---------------- D phase (train_fns.py:41-139)
+    _set_requires_grad(d, ts.d_params, True)
+    _set_requires_grad(g, ts.g_params, False)
+    d_grads, dv, emb_rs = over_events([g, d], lambda e: _d_phase_loss(ts, xs[e], y, noises[e]), (d, ts.d_params))
     if cfg.get("clip_norm") is not None:
         _clip(d_grads, cfg["clip_norm"])
     ts.d_step += 1
@@ -447,21 +529,12 @@ def train_step(ts: TrainState, x: Tensor, y: Tensor, noise: dict, itr: int = 1) 
     # ---------------- G phase (train_fns.py:142-192)
     _set_requires_grad(d, ts.d_params, False)
     _set_requires_grad(g, ts.g_params, True)
-    gz = generator(g, cfg, noise["z_g"], y, noise["rdof_g"], True)
-    if cfg.get("diff_aug", True):
-        gz = diff_augment(gz, noise["aug_g"])
-    proxy_f, emb_f, d_fake = discriminator(d, cfg, gz, y, True)
-    g_loss = hinge_gen(d_fake)
-    if cfg.get("contra_lambda", 1.0) != 0:
-        g_loss = g_loss + cfg["contra_lambda"] * contrastive_loss(emb_f, proxy_f)
-    iea = zero
-    if cfg.get("IEA_loss", False):
-        iea = iea_loss(emb_f, emb_r.detach())
-        g_loss = g_loss + cfg["IEA_lambda"] * iea
-        if cfg.get("Uniformity_loss", False):                                      # nested, :171-178
-            g_loss = g_loss + cfg["unif_lambda"] * unif_loss(emb_f)
-    grads = torch.autograd.grad(g_loss, [g[k] for k in ts.g_params], allow_unused=True)
-    g_grads = {k: (gr if gr is not None else torch.zeros_like(g[k])) for k, gr in zip(ts.g_params, grads)}
+
+    def g_loss_fn(e):
+        loss, iea = _g_phase_loss(ts, y, noises[e], emb_rs[e])
+        return loss, (iea,), None
+
+    g_grads, gv, _ = over_events([g, d], g_loss_fn, (g, ts.g_params))
     if cfg.get("G_ortho", 0.0) > 0.0:                                              # :185-188
         for k in ts.g_params:
             if g[k].dim() >= 2 and k != "shared.weight":
@@ -475,8 +548,18 @@ def train_step(ts: TrainState, x: Tensor, y: Tensor, noise: dict, itr: int = 1) 
     if cfg.get("ema", False) and ts.ema is not None:
         ema_update(ts.ema, {k: v.detach() for k, v in g.items()}, itr, cfg["ema_decay"], cfg["ema_start"])
     ts.last_grads = (g_grads, d_grads)
-    return {"G_loss": float(g_loss), "D_loss_real": float(l_real), "D_loss_fake": float(l_fake),
-            "unif_loss_d": float(unif_d), "iea_loss": float(iea)}
+    return {"G_loss": gv[1], "D_loss_real": dv[0], "D_loss_fake": dv[1], "unif_loss_d": dv[2], "iea_loss": gv[0]}
+
+
+def train_step(ts: TrainState, x: Tensor, y: Tensor, noise: dict, itr: int = 1) -> Dict[str, float]:
+    """One D update + one G update on one event (train_fns.py:23-205, Contra branch, split_D).
+
+    ``noise`` = {'z_d','rdof_d','aug_d' (dict|None), 'z_g','rdof_g','aug_g'[, 'cr']}: the explicit draws of
+    the D-phase and G-phase generator passes (and of CR_DiffAug with ``Con_reg``).  Config keys used: contra_lambda,
+    IEA_loss/IEA_lambda, Uniformity_loss/unif_lambda, diff_aug, Con_reg/cr_lambda, G_ortho, clip_norm, ema.  Terms
+    switched off contribute 0.0 to the returned dict (the reference raises UnboundLocalError there, SURVEY section
+    9-Q2).  ``clip_norm=None`` reproduces the reference quirk that G's optimiser never steps (9-Q1)."""
+    return train_step_events(ts, [x], y, [noise], itr)
 
 
 def _clip(grads: Dict[str, Tensor], max_norm: float) -> None:
@@ -522,10 +605,20 @@ def frechet_distance(mu1, sigma1, mu2, sigma2, eps: float = 1e-6) -> float:
 
 
 def generate_export(img: Tensor) -> Tensor:
+    """Post-processing of model.generate (model.py:1139-1147) on the generator output ``img`` [N,1,H,W] in [-1,1]:
+    cut below 7 ADU (threshold -0.26 -> -1), [-1,1] -> [0,1], 256**x - 1, clamp to [0,255], drop the channel axis and
+    the 3 padded rows either side -> [N, H-6, W].  Pinned bit-exactly by tests/golden/op_export.npz."""
     img = F.threshold(img, -0.26, -1)
-    img = img * 0.5 + 0.5
+    img = img.mul(0.5).add(0.5)
     img = torch.pow(256, img).add(-1).clamp(0, 255)
     return img[:, 0, 3:-3, :]
+
+
+def denorm(img: Tensor) -> Tensor:
+    """utils.norm.denorm (utils/norm.py:34-46): as above without the threshold, channel axis kept -> [N,1,H-6,W]."""
+    out = img.mul(0.5).add(0.5)
+    out = torch.pow(256, out).add(-1).clamp(0, 255)
+    return out[:, :, 3:-3, :]
 
 
 # --------------------------------------------------------------------------------------------

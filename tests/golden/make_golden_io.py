@@ -83,6 +83,31 @@ def main():
         cases[name] = ref
     np.savez_compressed(os.path.join(HERE, "op_frechet.npz"), a=a, b=b, c=c, **{"fd_" + k: np.float64(v) for k, v in cases.items()})
     print("wrote op_ingest.npz, op_frechet.npz", cases)
+    # ---- export step after the path: model.generate (model.py:1130-1148) and utils.norm.denorm (utils/norm.py:34-46)
+    # driven with a stand-in "generator" that returns a fixed image, so that only the export arithmetic is pinned:
+    # values around the -0.26 threshold (both sides and exactly on it), the clamp at 255 and the [-1, 1] end points
+    sys.path.insert(0, REF)
+    import pandas  # noqa: F401  (layers.py imports it for an unused helper)
+    import model as R_model
+    img = torch.from_numpy(rng.uniform(-1.0, 1.0, (40, 1, 16, 24)).astype(np.float32))
+    img[0, 0, 5, :6] = torch.tensor([-0.26, -0.2600001, -0.2599999, 1.0, -1.0, 0.999999])
+
+    class Fixed(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(1))
+
+        def forward(self, z, y):
+            assert z.shape == (40, 128) and y.tolist() == list(range(40))
+            return img.clone()
+
+    adu = R_model.generate(Fixed())
+    den = R_norm.denorm(img.clone())
+    assert adu.shape == (40, 10, 24) and den.shape == (40, 1, 10, 24)
+    assert torch.equal(O.generate_export(img), adu), "oracle generate_export != reference model.generate"
+    assert torch.equal(O.denorm(img), den), "oracle denorm != reference utils.norm.denorm"
+    np.savez_compressed(os.path.join(HERE, "op_export.npz"), img=img.numpy(), adu=adu.numpy(), denorm=den.numpy())
+    print("wrote op_export.npz")
 
 
 if __name__ == "__main__":

@@ -308,3 +308,55 @@ def test_ingest_and_frechet_against_reference_vectors(golden_dir):
         a, b = f[p], f[q]
         fd = O.frechet_distance(a.mean(0), np.cov(a, rowvar=False), b.mean(0), np.cov(b, rowvar=False))
         assert abs(fd - float(f["fd_" + name])) <= 1e-8 * max(1.0, abs(fd)), name
+
+
+def test_export_against_reference_vectors(golden_dir):
+    """model.generate's post-processing and utils.norm.denorm (fixture written by make_golden_io.py from the reference's
+    own functions): bit-exact, including pixels exactly on / either side of the -0.26 threshold."""
+    g = _load(golden_dir, "op_export.npz")
+    assert torch.equal(O.generate_export(g["img"]), g["adu"])
+    assert torch.equal(O.denorm(g["img"]), g["denorm"])
+    assert g["adu"].shape == (40, 10, 24) and float(g["adu"].min()) == 0.0 and float(g["adu"].max()) == 255.0
+
+
+def _cfg3_inputs(g, n=40, res=64):
+    E = int(g["E"])
+    noises = []
+    for e in range(E):
+        nz = {}
+        for k in g:
+            if not k.startswith(f"noise{e}_"):
+                continue
+            name = k[len(f"noise{e}_"):]
+            if "." in name:
+                a, b = name.split(".", 1)
+                nz.setdefault(a, {})[b] = g[k]
+            else:
+                nz[name] = g[k]
+        noises.append(nz)
+    return [O.synth_event(n, res, res, 303 + e) for e in range(E)], noises
+
+
+def test_train_step_events_con_reg_64(golden_dir, ref_cfg):
+    """BASELINE configs[3] semantics at 40x64x64: E = 2 events per step, DiffAugment + CR_DiffAug consistency
+    regularisation (third discriminator pass) + uniformity loss.  The fixture is the composition of the reference's own
+    modules (tests/golden/make_golden_cfg3.py); E = 1 of the same code path is pinned by test_train_step_64."""
+    g = _load(golden_dir, "step_64_cfg3.npz")
+    cfg = dict(ref_cfg, resolution=64, H_base=1, ema=False, clip_norm=1e9, Con_reg=True)
+    xs, noises = _cfg3_inputs(g)
+    g0, d0 = O.synth_nets(cfg, 101, 202)
+    gsd, gp = O.as_trainable(g0)
+    dsd, dp = O.as_trainable(d0)
+    ts = O.TrainState(gsd, dsd, gp, dp, cfg)
+    out = O.train_step_events(ts, xs, torch.arange(40), noises, itr=1)
+    for k, v in out.items():
+        ref = g["loss_" + k].item()
+        assert abs(v - ref) <= 2e-4 * max(1.0, abs(ref)), (k, v, ref)
+    g_grads, d_grads = ts.last_grads
+    _close(torch.tensor([g_grads[k].norm().item() for k in gp]), g["G_gradnorm"], tol=5e-4, what="G grad norms")
+    _close(torch.tensor([d_grads[k].norm().item() for k in dp]), g["D_gradnorm"], tol=5e-4, what="D grad norms")
+    for name, sd, spec in (("G", gsd, O.g_spec(cfg)), ("D", dsd, O.d_spec(cfg))):
+        sums = torch.tensor([sd[k].double().sum().item() for k in spec], dtype=torch.float64)
+        asums = torch.tensor([sd[k].double().abs().sum().item() for k in spec], dtype=torch.float64)
+        assert torch.allclose(sums, g[f"{name}_sum"], rtol=1e-4, atol=1e-3), name
+        assert torch.allclose(asums, g[f"{name}_abssum"], rtol=1e-4, atol=1e-3), name
