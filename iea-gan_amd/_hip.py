@@ -13,6 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libieagan_hip.so")
+CONV_FORCE_GATHER = 1   # ieagan_conv_desc.flags bit (tests): route a 3x3 layer through the gather kernel
 STAT_REPL = 32          # replicas of every (sum, sumsq) statistics buffer (common.h)
 SN_FIELDS = 16          # int64 fields per row of the spectral-norm layer table (sn.hip)
 
@@ -28,7 +29,7 @@ class ConvDesc(C.Structure):
     _fields_ = [("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
                 ("taps", C.c_int), ("Kpad", C.c_int), ("src", SrcDesc), ("w", vp), ("bias", vp),
                 ("ra", vp), ("Cra", C.c_int), ("Ca", C.c_int), ("ra_rs", C.c_int), ("ra_scale", C.c_float), ("rb", vp),
-                ("Crb", C.c_int), ("mask", vp), ("out", vp), ("stats", vp)]
+                ("Crb", C.c_int), ("mask", vp), ("out", vp), ("stats", vp), ("n_per_event", C.c_int), ("flags", C.c_int)]
 
 
 class WgradDesc(C.Structure):
@@ -42,7 +43,7 @@ class ProfRec(C.Structure):
                 ("flops", C.c_double), ("bytes", C.c_double)]
 
 
-ABI_VERSION = 2            # include/ieagan_hip.h: IEAGAN_ABI_VERSION
+ABI_VERSION = 3            # include/ieagan_hip.h: IEAGAN_ABI_VERSION
 i, f, l = C.c_int, C.c_float, C.c_long
 _SIGS = {
     "ieagan_abi_version": [],
@@ -50,14 +51,13 @@ _SIGS = {
     "ieagan_prof_reset": [],
     "ieagan_prof_collect": [C.POINTER(ProfRec), i],
     "ieagan_conv_forward": [C.POINTER(ConvDesc), vp],
-    "ieagan_conv_force_gather": [i],
     "ieagan_conv_wgrad": [C.POINTER(WgradDesc), i, vp],
-    "ieagan_effgrad": [vp, vp, vp, vp, vp, l, i, vp],
+    "ieagan_effgrad": [vp, vp, vp, vp, vp, l, i, i, vp],
     "ieagan_prologue_bwd": [vp, vp, i, vp, vp, i, i, i, vp, vp, vp, i, i, i, i, vp, i, i, i, vp],
-    "ieagan_bn_finalize_fwd": [vp, f, vp, vp, i, i, f, f, i, vp, vp, vp, vp, vp, i, i, vp],
-    "ieagan_bn_finalize_bwd": [vp, vp, vp, i, i, vp, f, i, vp, vp, i, vp, i, i, vp],
+    "ieagan_bn_finalize_fwd": [vp, f, vp, vp, i, i, f, f, i, vp, vp, vp, vp, vp, i, i, i, vp],
+    "ieagan_bn_finalize_bwd": [vp, vp, vp, i, i, vp, f, i, vp, vp, i, vp, i, i, i, vp],
     "ieagan_res_bwd": [vp, i, vp, i, i, i, i, i, i, vp],
-    "ieagan_nchw_to_nhwc": [vp, vp, vp, i, i, i, vp],
+    "ieagan_nchw_to_nhwc": [vp, vp, vp, i, i, i, i, vp],
     "ieagan_nhwc_to_nchw": [vp, vp, i, i, i, vp],
     "ieagan_channel_stats": [vp, vp, l, i, vp],
     "ieagan_conv_1toC": [vp, vp, vp, vp, vp, i, i, i, i, i, vp],

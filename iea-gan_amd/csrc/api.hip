@@ -108,12 +108,6 @@ extern "C" int ieagan_conv_forward(const ieagan_conv_desc* d, void* stream) {
     return conv_gather_launch(*d, (hipStream_t)stream);
 }
 
-void conv_force_gather(int on);
-extern "C" int ieagan_conv_force_gather(int on) {
-    conv_force_gather(on);
-    return 0;
-}
-
 extern "C" int ieagan_conv_wgrad(const ieagan_wgrad_desc* d, int use_tr_read, void* stream) {
     CHECK_ARG(d != nullptr && d->src.x != nullptr && d->g != nullptr && d->dw != nullptr, "conv_wgrad: null pointer");
     return conv_wgrad_launch(*d, (hipStream_t)stream, use_tr_read);

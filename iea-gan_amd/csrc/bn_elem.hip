@@ -43,6 +43,12 @@ __global__ __launch_bounds__(256) void effgrad_kernel(const bf16* __restrict__ d
     __shared__ float red[256 * 8];
     const int groups = C >> 3;                 // divides 256 (C in {16..512}, multiple of 16 ... checked on host)
     const int cg = threadIdx.x % groups;
+    // blockIdx.y = event: P pixels of this event, its own (dsum, dsumsq) row
+    const long ev_off = (long)blockIdx.y * P * C;
+    dout += ev_off;
+    if (out) out += ev_off;
+    if (geff) geff += ev_off;
+    if (dstat) dstat += (long)blockIdx.y * 2 * C;
     const long chunks = P * groups;
     float ds[8], dq[8], part[8];
 #pragma unroll
@@ -70,20 +76,24 @@ __global__ __launch_bounds__(256) void effgrad_kernel(const bf16* __restrict__ d
 #pragma unroll
         for (int i = 0; i < 8; ++i) part[i] += v[i];
     }
-    if (colsum) reduce_groups_atomic(part, groups, colsum + (long)(blockIdx.x % STAT_REPL) * C, red);
+    if (colsum) reduce_groups_atomic(part, groups, colsum + (long)((blockIdx.x + blockIdx.y) % STAT_REPL) * C, red);
 }
 
 extern "C" int ieagan_effgrad(const void* dout, const void* out, const float* dstat, void* geff, float* colsum,
-                              long P, int C, void* stream) {
+                              long P, int C, int E, void* stream) {
     CHECK_ARG(C % 8 == 0 && C <= 2048, "effgrad: C=%d must be a multiple of 8, <= 2048", C);
     CHECK_ARG(dstat == nullptr || (out != nullptr && geff != nullptr), "effgrad: dstat needs out and geff");
+    if (E < 1) E = 1;
+    CHECK_ARG(P % E == 0 && E <= 65535, "effgrad: %ld pixels are not %d whole events", P, E);
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof("effgrad", 0.0, (dstat ? 6.0 : 2.0) * P * C, st);
-    long blocks = (P * (C / 8) + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    const long Pe = P / E;
+    long blocks = (Pe * (C / 8) + 255) / 256;
+    const long cap = E > 1 ? (4096 / E > 64 ? 4096 / E : 64) : 2048;
+    if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(effgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const bf16*)dout, (const bf16*)out,
-                       dstat, (bf16*)geff, colsum, P, C);
+    hipLaunchKernelGGL(effgrad_kernel, dim3((unsigned)blocks, (unsigned)E), dim3(256), 0, st, (const bf16*)dout, (const bf16*)out,
+                       dstat, (bf16*)geff, colsum, Pe, C);
     CHECK_LAUNCH("effgrad");
     return 0;
 }
@@ -216,102 +226,133 @@ extern "C" int ieagan_prologue_bwd(const void* da, const void* x, int Cx, const 
 //   training: batch statistics + running-stat update (momentum, unbiased variance for the running
 //             update, as F.batch_norm); eval: running statistics
 // ------------------------------------------------------------------------------------------------
-// one wave per channel: lanes fold the statistics replicas, then fan out over the images
+// one wave per channel: lanes fold the statistics replicas of every event, then fan out over the images
 __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __restrict__ stats, float count, const float* __restrict__ gain,
                                        const float* __restrict__ bias, int ld, int plus_one, float eps, float momentum,
                                        int training, float* __restrict__ run_mean, float* __restrict__ run_var,
                                        float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_rstd,
-                                       int N, int C) {
+                                       int N, int C, int E) {
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
-    float mean, var;
-    if (training) {
-        float s1 = 0.f, s2 = 0.f;
-        for (int r = lane; r < STAT_REPL; r += 64) {
-            s1 += stats[(long)r * 2 * C + c];
-            s2 += stats[(long)r * 2 * C + C + c];
+    const int npe = N / E;
+    const int rows = (ld == 0 && E == 1) ? 1 : N;
+    float upd_mean = 0.f, upd_var = 0.f;
+    for (int e = 0; e < E; ++e) {
+        float mean, var;
+        if (training) {
+            float s1 = 0.f, s2 = 0.f;
+            const float* se = stats + (long)e * STAT_REPL * 2 * C;
+            for (int r = lane; r < STAT_REPL; r += 64) {
+                s1 += se[(long)r * 2 * C + c];
+                s2 += se[(long)r * 2 * C + C + c];
+            }
+            s1 = wave_sum(s1);
+            s2 = wave_sum(s2);
+            mean = s1 / count;
+            var = fmaxf(s2 / count - mean * mean, 0.f);
+            upd_mean += mean;
+            upd_var += var * (count / fmaxf(count - 1.f, 1.f));
+        } else {
+            mean = run_mean[c];
+            var = run_var[c];
         }
-        s1 = wave_sum(s1);
-        s2 = wave_sum(s2);
-        mean = s1 / count;
-        var = fmaxf(s2 / count - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + eps);
         if (lane == 0) {
-            run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * mean;
-            run_var[c] = (1.f - momentum) * run_var[c] + momentum * var * (count / fmaxf(count - 1.f, 1.f));
+            mean_rstd[(long)e * 2 * C + c] = mean;
+            mean_rstd[(long)e * 2 * C + C + c] = rstd;
         }
-    } else {
-        mean = run_mean[c];
-        var = run_var[c];
+        const int n0 = (rows == 1) ? 0 : e * npe, n1 = (rows == 1) ? 1 : (e + 1) * npe;
+        for (int n = n0 + lane; n < n1; n += 64) {
+            const float g = gain[(long)n * ld + c] + (plus_one ? 1.f : 0.f);
+            const float sc = rstd * g;
+            scale[(long)n * C + c] = sc;
+            shift[(long)n * C + c] = bias[(long)n * ld + c] - mean * sc;
+        }
     }
-    const float rstd = rsqrtf(var + eps);
-    if (lane == 0) {
-        mean_rstd[c] = mean;
-        mean_rstd[C + c] = rstd;
-    }
-    const int rows = (ld == 0) ? 1 : N;
-    for (int n = lane; n < rows; n += 64) {
-        const float g = gain[(long)n * ld + c] + (plus_one ? 1.f : 0.f);
-        const float sc = rstd * g;
-        scale[(long)n * C + c] = sc;
-        shift[(long)n * C + c] = bias[(long)n * ld + c] - mean * sc;
+    if (training && lane == 0) {     // mean of the E per-event momentum updates (E = 1: F.batch_norm's update)
+        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * upd_mean / (float)E;
+        run_var[c] = (1.f - momentum) * run_var[c] + momentum * upd_var / (float)E;
     }
 }
 
 extern "C" int ieagan_bn_finalize_fwd(const float* stats, float count, const float* gain, const float* bias, int ld,
                                       int plus_one, float eps, float momentum, int training, float* run_mean,
-                                      float* run_var, float* scale, float* shift, float* mean_rstd, int N, int C,
+                                      float* run_var, float* scale, float* shift, float* mean_rstd, int N, int C, int E,
                                       void* stream) {
     CHECK_ARG(!training || stats != nullptr, "bn_finalize: training mode needs batch statistics");
+    if (E < 1) E = 1;
+    CHECK_ARG(N % E == 0, "bn_finalize: %d images are not %d whole events", N, E);
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof("bn_finalize_fwd", 0.0, 0.0, st);
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, stats, count, gain, bias, ld, plus_one, eps,
-                       momentum, training, run_mean, run_var, scale, shift, mean_rstd, N, C);
+                       momentum, training, run_mean, run_var, scale, shift, mean_rstd, N, C, E);
     CHECK_LAUNCH("bn_finalize_fwd");
     return 0;
 }
 
-//   dscale/dshift [rows][C]  ->  dgain/dbias [rows][ld-strided slice] (ld==0: [C]), dstat [2][C]
+//   dscale/dshift [rows][C]  ->  dgain/dbias [rows][ld-strided slice] (ld==0: [C], summed over the rows), dstat [E][2][C]
 __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* __restrict__ dscale, const float* __restrict__ dshift,
                                        const float* __restrict__ gain, int ld, int plus_one, const float* __restrict__ mean_rstd,
                                        float count, int training, float* __restrict__ dgain, float* __restrict__ dbias, int ldd,
-                                       float* __restrict__ dstat, int N, int C) {
+                                       float* __restrict__ dstat, int N, int C, int E) {
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
-    const float mean = mean_rstd[c], rstd = mean_rstd[C + c];
-    const int rows = (ld == 0) ? 1 : N;
-    float drstd = 0.f, dmean = 0.f;
-    for (int n = lane; n < rows; n += 64) {
-        const float g = gain[(long)n * ld + c] + (plus_one ? 1.f : 0.f);
-        const float ds = dscale[(long)n * C + c], dt = dshift[(long)n * C + c];
-        const float e = ds - dt * mean;          // d/d(scale) with shift = bias - mean*scale folded in
-        dgain[(long)n * ldd + c] = e * rstd;
-        dbias[(long)n * ldd + c] = dt;
-        drstd += e * g;
-        dmean -= dt * rstd * g;
+    const int npe = N / E;
+    const int rows = (ld == 0 && E == 1) ? 1 : N;
+    float dg_sum = 0.f, db_sum = 0.f;            // ld == 0: per-channel parameters, summed over rows / events
+    for (int e = 0; e < E; ++e) {
+        const float mean = mean_rstd[(long)e * 2 * C + c], rstd = mean_rstd[(long)e * 2 * C + C + c];
+        float drstd = 0.f, dmean = 0.f;
+        const int n0 = (rows == 1) ? 0 : e * npe, n1 = (rows == 1) ? 1 : (e + 1) * npe;
+        for (int n = n0 + lane; n < n1; n += 64) {
+            const float g = gain[(long)n * ld + c] + (plus_one ? 1.f : 0.f);
+            const float ds = dscale[(long)n * C + c], dt = dshift[(long)n * C + c];
+            const float ee = ds - dt * mean;          // d/d(scale) with shift = bias - mean*scale folded in
+            if (ld != 0) {
+                dgain[(long)n * ldd + c] = ee * rstd;
+                dbias[(long)n * ldd + c] = dt;
+            } else {
+                dg_sum += ee * rstd;
+                db_sum += dt;
+            }
+            drstd += ee * g;
+            dmean -= dt * rstd * g;
+        }
+        drstd = wave_sum(drstd);
+        dmean = wave_sum(dmean);
+        if (dstat && lane == 0) {
+            float* de = dstat + (long)e * 2 * C;
+            if (training) {
+                const float dvar = -0.5f * rstd * rstd * rstd * drstd;
+                de[C + c] = dvar / count;                          // d sumsq
+                de[c] = (dmean - 2.f * mean * dvar) / count;       // d sum
+            } else {
+                de[c] = 0.f;
+                de[C + c] = 0.f;
+            }
+        }
     }
-    drstd = wave_sum(drstd);
-    dmean = wave_sum(dmean);
-    if (dstat && lane == 0) {
-        if (training) {
-            const float dvar = -0.5f * rstd * rstd * rstd * drstd;
-            dstat[C + c] = dvar / count;                          // d sumsq
-            dstat[c] = (dmean - 2.f * mean * dvar) / count;       // d sum
-        } else {
-            dstat[c] = 0.f;
-            dstat[C + c] = 0.f;
+    if (ld == 0) {
+        dg_sum = wave_sum(dg_sum);
+        db_sum = wave_sum(db_sum);
+        if (lane == 0) {
+            dgain[c] = dg_sum;
+            dbias[c] = db_sum;
         }
     }
 }
 
 extern "C" int ieagan_bn_finalize_bwd(const float* dscale, const float* dshift, const float* gain, int ld, int plus_one,
                                       const float* mean_rstd, float count, int training, float* dgain, float* dbias,
-                                      int ldd, float* dstat, int N, int C, void* stream) {
+                                      int ldd, float* dstat, int N, int C, int E, void* stream) {
+    if (E < 1) E = 1;
+    CHECK_ARG(N % E == 0, "bn_finalize_bwd: %d images are not %d whole events", N, E);
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof("bn_finalize_bwd", 0.0, 0.0, st);
     hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, dscale, dshift, gain, ld, plus_one,
-                       mean_rstd, count, training, dgain, dbias, ldd, dstat, N, C);
+                       mean_rstd, count, training, dgain, dbias, ldd, dstat, N, C, E);
     CHECK_LAUNCH("bn_finalize_bwd");
     return 0;
 }
@@ -378,7 +419,7 @@ extern "C" int ieagan_res_bwd(const void* g, int Cg, void* dr, int Cr, int Ca, i
 // bf16-rounded values for a BatchNorm that consumes the converted tensor.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, bf16* __restrict__ out,
-                                                           float* __restrict__ stats, int C, int HW) {
+                                                           float* __restrict__ stats, int C, int HW, int npe) {
     __shared__ float tile[32][33];
     const int n = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
@@ -399,7 +440,8 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
         }
     }
     if (stats != nullptr && c0 + tx < C) {
-        float* st = stats + (long)((blockIdx.x + blockIdx.z) % STAT_REPL) * 2 * C;
+        const int event = npe > 0 ? n / npe : 0;
+        float* st = stats + ((long)event * STAT_REPL + (blockIdx.x + blockIdx.z) % STAT_REPL) * 2 * C;
         atomicAdd(st + c0 + tx, s1);
         atomicAdd(st + C + c0 + tx, s2);
     }
@@ -420,10 +462,11 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const bf16* __restric
     }
 }
 
-extern "C" int ieagan_nchw_to_nhwc(const float* in, void* out, float* stats, int N, int C, int HW, void* stream) {
+extern "C" int ieagan_nchw_to_nhwc(const float* in, void* out, float* stats, int N, int C, int HW, int n_per_event, void* stream) {
+    CHECK_ARG(n_per_event >= 0 && (n_per_event == 0 || N % n_per_event == 0), "nchw_to_nhwc: N=%d is not a whole number of events of %d images", N, n_per_event);
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof("nchw_to_nhwc", 0.0, 6.0 * N * C * (double)HW, st);
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(HW, 32), cdiv(C, 32), N), dim3(256), 0, st, in, (bf16*)out, stats, C, HW);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(HW, 32), cdiv(C, 32), N), dim3(256), 0, st, in, (bf16*)out, stats, C, HW, n_per_event);
     CHECK_LAUNCH("nchw_to_nhwc");
     return 0;
 }

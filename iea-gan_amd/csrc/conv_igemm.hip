@@ -190,7 +190,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x4 (&a
 #define STATS_SX_FLOATS (8 * 64)           // per wave (sums and sums of squares take turns)
 template <int NT>
 __device__ __forceinline__ void stats_flush(const ConvArgs& a, float (&s1)[8], float (&s2)[8], int n_base, float* red /*[4][NT*16][2]*/,
-                                            float* sx_all /* 4 * STATS_SX_FLOATS, free at this point */, int replica) {
+                                            float* sx_all /* 4 * STATS_SX_FLOATS, free at this point */, int replica, int event) {
     constexpr int CPP = NT * 2;
     constexpr int SH = 64 / CPP;                      // lanes sharing a chunk
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -221,7 +221,7 @@ __device__ __forceinline__ void stats_flush(const ConvArgs& a, float (&s1)[8], f
             x1 += red[(wv * NT * 16 + t) * 2 + 0];
             x2 += red[(wv * NT * 16 + t) * 2 + 1];
         }
-        float* st = a.stats + (long)(replica % STAT_REPL) * 2 * a.Cout;
+        float* st = a.stats + ((long)event * STAT_REPL + replica % STAT_REPL) * 2 * a.Cout;
         atomicAdd(st + n_base + t, x1);
         atomicAdd(st + a.Cout + n_base + t, x2);
     }
@@ -324,7 +324,9 @@ __global__ __launch_bounds__(256, 4) void conv_gather_kernel(ConvArgs a) {
     static_assert(4 * EROWS * EpiLds<NT>::LDW >= 4 * STATS_SX_FLOATS, "epilogue buffer doubles as the statistics scratch");
     if (a.stats != nullptr) {
         __syncthreads();          // every wave is done with its part of the epilogue buffer, which now serves as fold scratch
-        stats_flush<NT>(a, s1, s2, n_base, red, epi, blockIdx.x);
+        // every 128-pixel block lies inside one event (launcher: n_per_event * H * W % 128 == 0 when E > 1)
+        const int event = (a.n_per_event > 0) ? (int)(((long)blockIdx.x * 128) / ((long)a.n_per_event * HW)) : 0;
+        stats_flush<NT>(a, s1, s2, n_base, red, epi, blockIdx.x, event);
     }
 }
 
@@ -474,9 +476,20 @@ __global__ __launch_bounds__(256, ((CIN >= 64 && PF == 0) ? 2 : (CIN == 16 ? 4 :
     const bf16* wrow = (const bf16*)a.w + (long)(col_ok ? n_base + lr : 0) * KP + lg * 8;
 
     if (PF > 0 && t0 < t1) load_tile(t0);
+    int cur_event = -1;
     for (int t = t0; t < t1; ++t) {
         int n, h0, w0;
         tile_coords(t, n, h0, w0);
+        if (a.stats != nullptr) {       // per-event statistics: a persistent block that walks into the next event flushes first
+            const int ev = (a.n_per_event > 0) ? n / a.n_per_event : 0;
+            if (ev != cur_event && cur_event >= 0) {
+                stats_flush<NT>(a, s1, s2, n_base, red, (float*)smem, bid, cur_event);
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
+            }
+            cur_event = ev;
+        }
         if (AFF && n != aff_n) {        // block-uniform: (re)load this image's scale / shift rows
             __syncthreads();
             stage_aff(aff_s, a.src, n, Cin);
@@ -632,7 +645,7 @@ __global__ __launch_bounds__(256, ((CIN >= 64 && PF == 0) ? 2 : (CIN == 16 ? 4 :
         }
         __syncthreads();      // every wave has left its epilogue buffer: the region is the next tile's halo / the fold scratch
     }
-    if (a.stats != nullptr) stats_flush<NT>(a, s1, s2, n_base, red, (float*)smem, bid);
+    if (a.stats != nullptr && cur_event >= 0) stats_flush<NT>(a, s1, s2, n_base, red, (float*)smem, bid, cur_event);
 }
 
 template <bool AFF, bool RELU, int RS>
@@ -692,9 +705,6 @@ static int launch_halo_pro(const ConvArgs& a, hipStream_t st) {
     return launch_halo_nt<false, false, RS>(a, st);
 }
 
-static int g_force_gather = 0;      // tests: run 3x3 layers through the gather kernel
-void conv_force_gather(int on) { g_force_gather = on; }
-
 int conv_gather_launch(const ConvArgs& a, hipStream_t st) {
     CHECK_ARG(a.taps == 1 || a.taps == 9, "conv: taps must be 1 or 9 (got %d)", a.taps);
     CHECK_ARG(a.Cin % 8 == 0 && a.Cout % 8 == 0, "conv: Cin/Cout must be multiples of 8 (%d,%d)", a.Cin, a.Cout);
@@ -708,13 +718,16 @@ int conv_gather_launch(const ConvArgs& a, hipStream_t st) {
     if (a.ra) CHECK_ARG(a.Ca <= a.Cout && a.Ca <= a.Cra && a.Ca % 8 == 0 && a.Cra % 8 == 0, "conv: residual channel slice out of range");
     if (a.ra && a.ra_rs == 1) CHECK_ARG(a.H % 2 == 0 && a.W % 2 == 0, "conv: upsampled residual needs even H, W");
     if (a.rb) CHECK_ARG(a.Crb % 8 == 0 && a.Crb >= a.Cout - a.Ca, "conv: bad residual-B channel count");
+    CHECK_ARG(a.n_per_event >= 0 && (a.n_per_event == 0 || a.N % a.n_per_event == 0), "conv: N=%d is not a whole number of events of %d images", a.N, a.n_per_event);
+    if (a.stats != nullptr && a.n_per_event > 0 && a.n_per_event < a.N)
+        CHECK_ARG(((long)a.n_per_event * a.H * a.W) % 128 == 0, "conv: per-event statistics need n_per_event*H*W %% 128 == 0 (%d*%d*%d)", a.n_per_event, a.H, a.W);
     const double flops = 2.0 * a.N * a.H * a.W * (double)a.Cout * a.taps * a.Cin;
     // algorithmic bytes: source + output + the epilogue operands (ReLU mask, residual slices at their own resolution)
     double bytes = 2.0 * a.N * ((double)a.src.Hs * a.src.Ws * a.Cin + (double)a.H * a.W * a.Cout);
     if (a.mask) bytes += 2.0 * a.N * (double)a.H * a.W * a.Cout;
     if (a.ra) bytes += 2.0 * a.N * (double)a.H * a.W * a.Ca * (a.ra_rs == 1 ? 0.25 : (a.ra_rs == 2 ? 4.0 : 1.0));
     if (a.rb) bytes += 2.0 * a.N * (double)a.H * a.W * (a.Cout - a.Ca);
-    const bool halo = a.taps == 9 && a.src.rs != 2 && a.W >= 16 && a.H >= 4 && a.Cin % 16 == 0 && !g_force_gather &&
+    const bool halo = a.taps == 9 && a.src.rs != 2 && a.W >= 16 && a.H >= 4 && a.Cin % 16 == 0 && !(a.flags & IEAGAN_CONV_FORCE_GATHER) &&
                       (size_t)(HT_H + 2) * (HT_W + 2) * (a.Cin * 2 + 16) <= 150 * 1024 && a.Cin <= AFF_MAXC;
     char tag[64] = "";
     if (prof_tags_on())

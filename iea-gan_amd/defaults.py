@@ -44,6 +44,7 @@ def default_config() -> dict:
              trunc_z=0.5, denoise=False, metric_log_name="metric_log.jsonl",
              reinitialize_metric_logs=False, reinitialize_parameter_logs=False, num_incep_images=16000,
              load_optim=True)
-    # -- the one key that exists only here (default = reference behaviour)
+    # -- keys that exist only here (defaults = reference behaviour)
     c.update(hip_graph=False)            # replay the train step from captured HIP graphs (one graph; three in data-parallel runs)
+    c.update(events_per_step=1)          # E events of batch_size images per GPU and step (BASELINE configs[3])
     return c

@@ -202,10 +202,11 @@ class ccbn(nn.Module):
         self.register_buffer("stored_mean", torch.zeros(output_size))
         self.register_buffer("stored_var", torch.ones(output_size))
 
-    def scale_shift(self, stats, bank, col_gain, col_bias, count):
-        """Per-(n,c) scale / shift from the producer's statistics and the generator-wide gain bank."""
+    def scale_shift(self, stats, bank, col_gain, col_bias, count, events=1):
+        """Per-(n,c) scale / shift from the producer's per-event statistics and the generator-wide gain bank
+        (``count``: elements per channel of one event)."""
         return ops.BNFinalizeFn.apply(stats, bank.gb, bank, col_gain, col_bias, self.output_size, self.stored_mean,
-                                      self.stored_var, count, self.eps, 0.1, self.training)
+                                      self.stored_var, count, self.eps, 0.1, self.training, events)
 
     def forward(self, x, y):
         """Stand-alone ccbn (NCHW fp32 in/out): statistics + apply as two HIP passes."""
@@ -234,9 +235,9 @@ class bn(nn.Module):
         self.register_buffer("stored_mean", torch.zeros(output_size))
         self.register_buffer("stored_var", torch.ones(output_size))
 
-    def scale_shift(self, stats, count):
+    def scale_shift(self, stats, count, events=1, n_images=1):
         return ops.BNFinalizePlainFn.apply(stats, self.gain, self.bias, self.stored_mean, self.stored_var, count, self.eps,
-                                           self.momentum, self.training)
+                                           self.momentum, self.training, events, n_images)
 
     def forward(self, x, y=None):
         H.require_gpu()

@@ -69,6 +69,13 @@ def _activation(name):
     raise NotImplementedError(f"activation function {name} not implemented on the MI355X path (ReLU is fused into the convs)")
 
 
+def _n_events(net, n_images):
+    """Number of independent events in a batch of ``n_images``: ``events_per_step`` when the batch is exactly that many
+    events of ``event_size`` images, else 1 (the whole batch is one event, as in the reference)."""
+    E = net.events_per_step
+    return E if (E > 1 and n_images == E * net.event_size) else 1
+
+
 def _sn_children(module, prefix):
     """(state-dict prefix, layer) for every spectrally normalised layer below ``module``."""
     out = []
@@ -100,23 +107,25 @@ class GBlock(nn.Module):
         self.conv4 = which_conv(hid, out_channels, kernel_size=1, padding=0)
         self.bn1, self.bn2, self.bn3, self.bn4 = which_bn(in_channels), which_bn(hid), which_bn(hid), which_bn(hid)
 
-    def fused(self, xa, xstats, bank, cols, recs, prefix, want_stats=True):
-        """xa bf16 [N,H,W,Cin] with its (sum, sumsq) statistics -> (out bf16, out statistics)."""
+    def fused(self, xa, xstats, bank, cols, recs, prefix, want_stats=True, events=1):
+        """xa bf16 [N,H,W,Cin] with its per-event (sum, sumsq) statistics -> (out bf16, out statistics).  ``events``: the
+        batch holds that many events of N / events images; every BatchNorm normalises within its event."""
         N, Hh, Ww, _ = xa.shape
         up = 1 if self.upsample else 0
-        cnt = N * Hh * Ww
+        cnt = (N // events) * Hh * Ww
         tr = self.training
+        E = events
         link = ops.ResLink() if (torch.is_grad_enabled() and ops.FUSE_SHORTCUT_GRAD) else None   # conv4 -> conv1, in-kernel
-        s, t = self.bn1.scale_shift(xstats, bank, *cols["bn1"], cnt)
-        h, st = self.conv1.fused(xa, recs[prefix + ".conv1"], scale=s, shift=t, relu=True, want_stats=tr, res_in=link)
-        s, t = self.bn2.scale_shift(st, bank, *cols["bn2"], cnt)
-        h, st = self.conv2.fused(h, recs[prefix + ".conv2"], scale=s, shift=t, relu=True, rs=up, want_stats=tr)
+        s, t = self.bn1.scale_shift(xstats, bank, *cols["bn1"], cnt, E)
+        h, st = self.conv1.fused(xa, recs[prefix + ".conv1"], scale=s, shift=t, relu=True, want_stats=tr, res_in=link, events=E)
+        s, t = self.bn2.scale_shift(st, bank, *cols["bn2"], cnt, E)
+        h, st = self.conv2.fused(h, recs[prefix + ".conv2"], scale=s, shift=t, relu=True, rs=up, want_stats=tr, events=E)
         cnt2 = cnt * (4 if up else 1)
-        s, t = self.bn3.scale_shift(st, bank, *cols["bn3"], cnt2)
-        h, st = self.conv3.fused(h, recs[prefix + ".conv3"], scale=s, shift=t, relu=True, want_stats=tr)
-        s, t = self.bn4.scale_shift(st, bank, *cols["bn4"], cnt2)
+        s, t = self.bn3.scale_shift(st, bank, *cols["bn3"], cnt2, E)
+        h, st = self.conv3.fused(h, recs[prefix + ".conv3"], scale=s, shift=t, relu=True, want_stats=tr, events=E)
+        s, t = self.bn4.scale_shift(st, bank, *cols["bn4"], cnt2, E)
         return self.conv4.fused(h, recs[prefix + ".conv4"], scale=s, shift=t, relu=True, ra=xa, Ca=self.out_channels,
-                                ra_rs=up, want_stats=want_stats and tr, res_out=link)
+                                ra_rs=up, want_stats=want_stats and tr, res_out=link, events=E)
 
     def forward(self, x, y):
         """Stand-alone block on NCHW fp32 ``x`` with the conditioning vector ``y`` [N, cond]."""
@@ -141,8 +150,11 @@ class Generator(nn.Module):
                  rdof_dim=4, hier=True, cross_replica=False, mybn=False, G_activation="relu", G_lr=5e-5, G_B1=0.0,
                  G_B2=0.999, adam_eps=1e-8, BN_eps=1e-5, SN_eps=1e-12, G_init="ortho", G_mixed_precision=False,
                  G_fp16=False, skip_init=False, no_optim=False, sched_version="default", RRM_prx_G=True,
-                 prior_embed=False, n_head_G=2, G_param="SN", norm_style="bn", device="cuda", **kwargs):
+                 prior_embed=False, n_head_G=2, G_param="SN", norm_style="bn", device="cuda", events_per_step=1, **kwargs):
         super().__init__()
+        # E events per forward batch: a batch of exactly E * event_size images is E independent events
+        self.events_per_step = max(int(events_per_step or 1), 1)
+        self.event_size = int(kwargs.get("batch_size") or n_classes)
         if G_param != "SN" or not G_shared or not hier or not RRM_prx_G or prior_embed:
             raise NotImplementedError("MI355X Generator: G_param='SN', G_shared, hier, RRM_prx_G, no prior_embed "
                                       "(the configuration the reference ships)")
@@ -238,24 +250,25 @@ class Generator(nn.Module):
         plan = self._prepare()
         recs = plan["bank"].run(self.training, self.SN_eps)
         N = y.size(0)
+        E = _n_events(self, N)
         ye = self.shared(y)
         if rdof is None:
             rdof = self.__dict__.pop("_next_rdof", None)    # explicit draw injected by a parity test
         if rdof is None:   # the reference draws a fixed 40 rows here (model.py:466); we follow the batch
             rdof = torch.randn(N, self.rdof_dim, device=z.device)
         ye = self.linear_f.fused(torch.cat([ye, rdof], 1), recs["linear_f"])
-        ye = self.RR_G(ye.unsqueeze(0)).squeeze(0)
+        ye = self.RR_G(ye.view(E, N // E, -1)).reshape(N, -1)          # the sensors of ONE event are the RRM's tokens
         zc = torch.cat([ye, z], 1)
         gb = ops.StackedSNLinearFn.apply(zc, recs["__stack__"], recs, plan, *plan["stack_weights"])
         bank = ops.GainBank(gb, plan["n_bn"])
         h = self.linear.fused(zc, recs["linear"])
         h = h.view(N, -1, self.bottom_width, self.bottom_width * self.H_base)
-        xa, st = ops.ToNHWCFn.apply(h, self.training)
+        xa, st = ops.ToNHWCFn.apply(h, self.training, E)
         for bi, bl in enumerate(self.blocks):
-            xa, st = bl[0].fused(xa, st, bank, plan["cols"][bi], recs, f"blocks.{bi}.0")
+            xa, st = bl[0].fused(xa, st, bank, plan["cols"][bi], recs, f"blocks.{bi}.0", events=E)
         bn_out, conv_out = self.output_layer[0], self.output_layer[2]
         Nn, Hh, Ww, _ = xa.shape
-        s, t = bn_out.scale_shift(st, Nn * Hh * Ww)
+        s, t = bn_out.scale_shift(st, (Nn // E) * Hh * Ww, E, Nn)
         if export:
             if torch.is_grad_enabled() and any(p.requires_grad for p in (conv_out.weight,)) and xa.requires_grad:
                 raise RuntimeError("Generator(export=True) is an inference path: call it under torch.no_grad()")
@@ -309,8 +322,10 @@ class Discriminator(nn.Module):
                  D_B1=0.0, D_B2=0.999, adam_eps=1e-8, SN_eps=1e-12, output_dim=1, D_init="ortho", D_mixed_precision=False,
                  D_fp16=False, sched_version="default", skip_init=False, D_param="SN", hypersphere_dim=512,
                  nonlinear_embed=False, normalize_embed=True, prior_embed=False, RRM_prx_D=False, RRM_embed=False,
-                 n_head_D=4, **kwargs):
+                 n_head_D=4, events_per_step=1, **kwargs):
         super().__init__()
+        self.events_per_step = max(int(events_per_step or 1), 1)
+        self.event_size = int(kwargs.get("batch_size") or n_classes)
         if D_param != "SN" or prior_embed or RRM_prx_D or nonlinear_embed or attn_type != "sa":
             raise NotImplementedError("MI355X Discriminator: D_param='SN', attn_type='sa', no prior_embed / RRM_prx_D / "
                                       "nonlinear_embed (the configuration the reference ships)")
@@ -389,7 +404,9 @@ class Discriminator(nn.Module):
             out = torch.squeeze(self.linear0.fused(h, recs["linear0"]))
             proxy = self.embed.fused(y, recs["embed"])
             if self.RRM_embed:
-                h = self.RR_D(h.unsqueeze(0), recs=recs, prefix="RR_D").squeeze(0)
+                N = h.shape[0]
+                E = _n_events(self, N)
+                h = self.RR_D(h.view(E, N // E, -1), recs=recs, prefix="RR_D").reshape(N, -1)
                 emb = self.norm(self.linear1.fused(h, recs["linear1"]))
             else:
                 emb = self.linear1.fused(h, recs["linear1"])

@@ -70,8 +70,9 @@ def zeros(shape, device) -> torch.Tensor:
     return _ZEROS.take(n, device).view(shape)
 
 
-def new_stats(C: int, device) -> torch.Tensor:
-    return zeros((STAT_REPL, 2, C), device)
+def new_stats(C: int, device, events: int = 1) -> torch.Tensor:
+    """Zeroed per-event replicated (sum, sumsq) accumulators: [E, STAT_REPL, 2, C]."""
+    return zeros((events, STAT_REPL, 2, C), device)
 
 
 # When True (set by the train step around ``backward()``), gradients of spectrally normalised weights
@@ -381,16 +382,17 @@ class BNFinalizeFn(torch.autograd.Function):
     """ccbn: scale = rstd*(1+gain[n,c]), shift = bias[n,c] - mean*scale  (layers.py:656-689)."""
 
     @staticmethod
-    def forward(ctx, stats, gb, bank, col_gain, col_bias, C, run_mean, run_var, count, eps, momentum, training):
+    def forward(ctx, stats, gb, bank, col_gain, col_bias, C, run_mean, run_var, count, eps, momentum, training, events=1):
+        """``count``: elements per channel of ONE event; ``stats`` [E, STAT_REPL, 2, C]."""
         N, ld = gb.shape
         dev = gb.device
         scale = torch.empty(N, C, dtype=torch.float32, device=dev)
         shift = torch.empty(N, C, dtype=torch.float32, device=dev)
-        mr = torch.empty(2, C, dtype=torch.float32, device=dev)
+        mr = torch.empty(events, 2, C, dtype=torch.float32, device=dev)
         H.call("ieagan_bn_finalize_fwd", H.ptr(stats), float(count), gb.data_ptr() + 4 * col_gain,
                gb.data_ptr() + 4 * col_bias, ld, 1, float(eps), float(momentum), int(training), run_mean.data_ptr(),
-               run_var.data_ptr(), scale.data_ptr(), shift.data_ptr(), mr.data_ptr(), N, C, H.stream())
-        ctx.bank, ctx.cols, ctx.C, ctx.count, ctx.training = bank, (col_gain, col_bias), C, count, training
+               run_var.data_ptr(), scale.data_ptr(), shift.data_ptr(), mr.data_ptr(), N, C, events, H.stream())
+        ctx.bank, ctx.cols, ctx.C, ctx.count, ctx.training, ctx.events = bank, (col_gain, col_bias), C, count, training, events
         ctx.has_stats = stats is not None
         ctx.save_for_backward(gb, mr)
         return scale, shift
@@ -402,32 +404,37 @@ class BNFinalizeFn(torch.autograd.Function):
         C = ctx.C
         bank = ctx.bank
         gbuf = bank.grad_buffer()
-        dstat = torch.empty(2, C, dtype=torch.float32, device=gb.device)
+        E = ctx.events
+        dstat = torch.empty(E, 2, C, dtype=torch.float32, device=gb.device)
         dscale = dscale.contiguous() if dscale is not None else torch.zeros(N, C, device=gb.device)
         dshift = dshift.contiguous() if dshift is not None else torch.zeros(N, C, device=gb.device)
         H.call("ieagan_bn_finalize_bwd", dscale.data_ptr(), dshift.data_ptr(), gb.data_ptr() + 4 * ctx.cols[0], ld, 1,
                mr.data_ptr(), float(ctx.count), int(ctx.training), gbuf.data_ptr() + 4 * ctx.cols[0],
-               gbuf.data_ptr() + 4 * ctx.cols[1], ld, dstat.data_ptr(), N, C, H.stream())
+               gbuf.data_ptr() + 4 * ctx.cols[1], ld, dstat.data_ptr(), N, C, E, H.stream())
         bank.pending -= 1
         dgb = gbuf if bank.pending == 0 else None
-        dstats = dstat.unsqueeze(0).expand(STAT_REPL, 2, C) if (ctx.has_stats and ctx.training) else None
-        return dstats, dgb, None, None, None, None, None, None, None, None, None, None
+        dstats = dstat.unsqueeze(1).expand(E, STAT_REPL, 2, C) if (ctx.has_stats and ctx.training) else None
+        return dstats, dgb, None, None, None, None, None, None, None, None, None, None, None
 
 
 class BNFinalizePlainFn(torch.autograd.Function):
     """layers.bn: per-channel gain / bias parameters (layers.py:728-742)."""
 
     @staticmethod
-    def forward(ctx, stats, gain, bias, run_mean, run_var, count, eps, momentum, training):
+    def forward(ctx, stats, gain, bias, run_mean, run_var, count, eps, momentum, training, events=1, n_images=1):
+        """One event: per-channel scale / shift [C].  E > 1 events: one row per image, [N, C] (every image takes the
+        statistics of its own event)."""
         C = gain.numel()
         dev = gain.device
-        scale = torch.empty(C, dtype=torch.float32, device=dev)
-        shift = torch.empty(C, dtype=torch.float32, device=dev)
-        mr = torch.empty(2, C, dtype=torch.float32, device=dev)
+        rows = 1 if events == 1 else n_images
+        shape = (C,) if rows == 1 else (rows, C)
+        scale = torch.empty(shape, dtype=torch.float32, device=dev)
+        shift = torch.empty(shape, dtype=torch.float32, device=dev)
+        mr = torch.empty(events, 2, C, dtype=torch.float32, device=dev)
         H.call("ieagan_bn_finalize_fwd", H.ptr(stats), float(count), gain.data_ptr(), bias.data_ptr(), 0, 0, float(eps),
                float(momentum), int(training), run_mean.data_ptr(), run_var.data_ptr(), scale.data_ptr(),
-               shift.data_ptr(), mr.data_ptr(), 1, C, H.stream())
-        ctx.count, ctx.training, ctx.has_stats = count, training, stats is not None
+               shift.data_ptr(), mr.data_ptr(), rows, C, events, H.stream())
+        ctx.count, ctx.training, ctx.has_stats, ctx.events, ctx.rows = count, training, stats is not None, events, rows
         ctx.save_for_backward(gain, mr)
         return scale, shift
 
@@ -436,24 +443,27 @@ class BNFinalizePlainFn(torch.autograd.Function):
         gain, mr = ctx.saved_tensors
         C = gain.numel()
         dev = gain.device
+        E, rows = ctx.events, ctx.rows
         dgain, dbias = torch.empty_like(gain), torch.empty_like(gain)
-        dstat = torch.empty(2, C, dtype=torch.float32, device=dev)
-        dscale = dscale.contiguous() if dscale is not None else torch.zeros(C, device=dev)
-        dshift = dshift.contiguous() if dshift is not None else torch.zeros(C, device=dev)
+        dstat = torch.empty(E, 2, C, dtype=torch.float32, device=dev)
+        shape = (C,) if rows == 1 else (rows, C)
+        dscale = dscale.contiguous() if dscale is not None else torch.zeros(shape, device=dev)
+        dshift = dshift.contiguous() if dshift is not None else torch.zeros(shape, device=dev)
         H.call("ieagan_bn_finalize_bwd", dscale.data_ptr(), dshift.data_ptr(), gain.data_ptr(), 0, 0, mr.data_ptr(),
-               float(ctx.count), int(ctx.training), dgain.data_ptr(), dbias.data_ptr(), 0, dstat.data_ptr(), 1, C, H.stream())
-        dstats = dstat.unsqueeze(0).expand(STAT_REPL, 2, C) if (ctx.has_stats and ctx.training) else None
-        return dstats, dgain, dbias, None, None, None, None, None, None
+               float(ctx.count), int(ctx.training), dgain.data_ptr(), dbias.data_ptr(), 0, dstat.data_ptr(), rows, C, E,
+               H.stream())
+        dstats = dstat.unsqueeze(1).expand(E, STAT_REPL, 2, C) if (ctx.has_stats and ctx.training) else None
+        return dstats, dgain, dbias, None, None, None, None, None, None, None, None
 
 
 # =====================================================================================================
 # Fused convolution
 # =====================================================================================================
 def _conv_launch(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu, N, Hc, Wc, Cin, Cout, taps, kpad, w, bias,
-                 ra, Cra, Ca, ra_rs, rb, Crb, mask, out, stats, ra_scale=1.0):
+                 ra, Cra, Ca, ra_rs, rb, Crb, mask, out, stats, ra_scale=1.0, npe=0, flags=0):
     d = H.ConvDesc(N, Hc, Wc, Cin, Cout, taps, kpad, H.src_desc(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu),
                    H.ptr(w), H.ptr(bias), H.ptr(ra), Cra, Ca, ra_rs, float(ra_scale), H.ptr(rb), Crb, H.ptr(mask),
-                   H.ptr(out), H.ptr(stats))
+                   H.ptr(out), H.ptr(stats), int(npe), int(flags))
     H.call("ieagan_conv_forward", d, H.stream())
 
 
@@ -486,17 +496,19 @@ class ResLink:
 
 class ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, scale, shift, ra, rb, rec, taps, rs, relu, Ca, ra_rs, want_stats, res_out, res_in):
+    def forward(ctx, x, weight, bias, scale, shift, ra, rb, rec, taps, rs, relu, Ca, ra_rs, want_stats, res_out, res_in, events=1):
         N, Hs, Ws, Cx = x.shape
         Cout, Cin = rec.out, rec.cin
         assert x.dtype == BF16 and x.is_contiguous() and Cx == Cin, (x.dtype, x.shape, Cin)
+        assert N % events == 0, (N, events)
         Hc, Wc = (2 * Hs, 2 * Ws) if rs == 1 else (Hs // 2, Ws // 2) if rs == 2 else (Hs, Ws)
         out = torch.empty(N, Hc, Wc, Cout, dtype=BF16, device=x.device)
-        stats = new_stats(Cout, x.device) if want_stats else None
+        stats = new_stats(Cout, x.device, events) if want_stats else None
         nstride = 0 if (scale is None or scale.dim() == 1) else scale.shape[1]
         _conv_launch(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu, N, Hc, Wc, Cin, Cout, taps, rec.kpad, rec.w_fwd,
                      bias, ra, ra.shape[-1] if ra is not None else 0, Ca, ra_rs, rb,
-                     rb.shape[-1] if rb is not None else 0, None, out, stats)
+                     rb.shape[-1] if rb is not None else 0, None, out, stats, npe=N // events)
+        ctx.events = events
         ctx.rec, ctx.cfg = rec, (taps, rs, relu, Ca, ra_rs, nstride, Hc, Wc)
         ctx.ra_shape = ra.shape if ra is not None else None
         ctx.has = (bias is not None, scale is not None, ra is not None, rb is not None)
@@ -535,15 +547,15 @@ class ConvFn(torch.autograd.Function):
             colsum = None
             if has_bias:
                 colsum = sn_scratch(rec, "b", (STAT_REPL, Cout), dev) if (need[1] and need[2]) else zeros((STAT_REPL, Cout), dev)
-            H.call("ieagan_effgrad", g.data_ptr(), out.data_ptr(), dstats[0].contiguous().data_ptr(), geff.data_ptr(),
-                   H.ptr(colsum), P, Cout, H.stream())
+            H.call("ieagan_effgrad", g.data_ptr(), out.data_ptr(), dstats[:, 0].contiguous().data_ptr(), geff.data_ptr(),
+                   H.ptr(colsum), P, Cout, ctx.events, H.stream())
             g = geff
         elif has_bias and need[2]:
             colsum = sn_scratch(rec, "b", (STAT_REPL, Cout), dev) if need[1] else zeros((STAT_REPL, Cout), dev)
             if need[1]:
                 colsum_in_wgrad = True      # the wgrad kernel stages every g tile anyway: it takes the column sums along
             else:
-                H.call("ieagan_effgrad", g.data_ptr(), None, None, None, colsum.data_ptr(), P, Cout, H.stream())
+                H.call("ieagan_effgrad", g.data_ptr(), None, None, None, colsum.data_ptr(), P, Cout, 1, H.stream())
         # ---- residual operands
         d_ra = d_rb = None
         if has_ra and need[5]:
@@ -616,12 +628,14 @@ class ConvFn(torch.autograd.Function):
             dW, dbias = sn_backward(dwp, weight, rec, colsum if (has_bias and need[2]) else None, ctx.bias_ref)
         elif has_bias and need[2]:
             dbias = colsum.sum(0)
-        return dx, dW, dbias, dscale, dshift, d_ra, d_rb, None, None, None, None, None, None, None, None, None
+        return dx, dW, dbias, dscale, dshift, d_ra, d_rb, None, None, None, None, None, None, None, None, None, None
 
 
 def conv(x, weight, bias, rec, taps, *, scale=None, shift=None, relu=False, rs=0, ra=None, Ca=0, ra_rs=0, rb=None,
-         want_stats=False, res_out=None, res_in=None):
-    return ConvFn.apply(x, weight, bias, scale, shift, ra, rb, rec, taps, rs, relu, Ca, ra_rs, want_stats, res_out, res_in)
+         want_stats=False, res_out=None, res_in=None, events=1):
+    """``events``: the batch holds that many events of N / events images each; the statistics of the output are taken per
+    event ([E, STAT_REPL, 2, Cout])."""
+    return ConvFn.apply(x, weight, bias, scale, shift, ra, rb, rec, taps, rs, relu, Ca, ra_rs, want_stats, res_out, res_in, events)
 
 
 # =====================================================================================================
@@ -654,7 +668,7 @@ class InputConvFn(torch.autograd.Function):
         dimg = dW = dbias = colsum = None
         if need[2]:
             colsum = sn_scratch(rec, "b", (STAT_REPL, C), dev) if need[1] else zeros((STAT_REPL, C), dev)
-            H.call("ieagan_effgrad", g.data_ptr(), None, None, None, colsum.data_ptr(), N * Hh * Ww, C, H.stream())
+            H.call("ieagan_effgrad", g.data_ptr(), None, None, None, colsum.data_ptr(), N * Hh * Ww, C, 1, H.stream())
         if need[0]:
             dimg = torch.empty(N, 1, Hh, Ww, dtype=torch.float32, device=dev)
             H.call("ieagan_conv_Cto1", g.data_ptr(), None, None, 0, 0, rec.w_plain.data_ptr(), None, dimg.data_ptr(), 0, N, Hh,
@@ -676,7 +690,8 @@ class OutputConvFn(torch.autograd.Function):
     def forward(ctx, h, scale, shift, weight, bias, rec):
         N, Hh, Ww, C = h.shape
         y = torch.empty(N, 1, Hh, Ww, dtype=torch.float32, device=h.device)
-        H.call("ieagan_conv_Cto1", h.data_ptr(), scale.data_ptr(), shift.data_ptr(), 0, 1, rec.w_plain.data_ptr(), H.ptr(bias),
+        ns = 0 if scale.dim() == 1 else C           # per-image rows when the batch holds several events
+        H.call("ieagan_conv_Cto1", h.data_ptr(), scale.data_ptr(), shift.data_ptr(), ns, 1, rec.w_plain.data_ptr(), H.ptr(bias),
                y.data_ptr(), 1, N, Hh, Ww, C, 0, H.stream())
         ctx.rec = rec
         ctx.save_for_backward(h, scale, shift, weight, y)
@@ -698,13 +713,14 @@ class OutputConvFn(torch.autograd.Function):
             H.call("ieagan_conv_1toC", dpre.data_ptr(), None, rec.w_plain.data_ptr(), None, da.data_ptr(), N, Hh, Ww, C, 1,
                    H.stream())
             dh = torch.empty_like(h)
+            ns = 0 if scale.dim() == 1 else C
             dscale, dshift = zeros(scale.shape, dev), zeros(shift.shape, dev)
-            H.call("ieagan_prologue_bwd", da.data_ptr(), h.data_ptr(), C, scale.data_ptr(), shift.data_ptr(), 0, 1, 0,
+            H.call("ieagan_prologue_bwd", da.data_ptr(), h.data_ptr(), C, scale.data_ptr(), shift.data_ptr(), ns, 1, 0,
                    dh.data_ptr(), dscale.data_ptr(), dshift.data_ptr(), N, Hh, Ww, C, None, 0, 0, 0, H.stream())
         if need[3]:
             dw = sn_scratch(rec, "w", (9, C), dev)
-            H.call("ieagan_wgrad_c1", dpre.data_ptr(), None, h.data_ptr(), scale.data_ptr(), shift.data_ptr(), 0, 1, dw.data_ptr(),
-                   N, Hh, Ww, C, 1, H.stream())
+            H.call("ieagan_wgrad_c1", dpre.data_ptr(), None, h.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                   0 if scale.dim() == 1 else C, 1, dw.data_ptr(), N, Hh, Ww, C, 1, H.stream())
             dW = sn_backward(dw, weight, rec)[0]
         return dh, dscale, dshift, dW, dbias, None
 
@@ -714,7 +730,7 @@ def output_conv_export(h, scale, shift, rec, bias):
     256^((x+1)/2) - 1 + clamp + crop -> detector units, fp32 [N, H-6, W] (inference only, no autograd)."""
     N, Hh, Ww, C = h.shape
     out = torch.empty(N, Hh - 6, Ww, dtype=torch.float32, device=h.device)
-    H.call("ieagan_conv_Cto1", h.data_ptr(), scale.data_ptr(), shift.data_ptr(), 0, 1, rec.w_plain.data_ptr(), H.ptr(bias),
+    H.call("ieagan_conv_Cto1", h.data_ptr(), scale.data_ptr(), shift.data_ptr(), 0 if scale.dim() == 1 else C, 1, rec.w_plain.data_ptr(), H.ptr(bias),
            out.data_ptr(), 2, N, Hh, Ww, C, 0, H.stream())
     return out
 
@@ -726,12 +742,13 @@ class ToNHWCFn(torch.autograd.Function):
     """fp32 NCHW -> bf16 NHWC (+ batch statistics of the result)."""
 
     @staticmethod
-    def forward(ctx, x, want_stats):
+    def forward(ctx, x, want_stats, events=1):
         N, C, Hh, Ww = x.shape
         x = x.contiguous().float()
         out = torch.empty(N, Hh, Ww, C, dtype=BF16, device=x.device)
-        stats = new_stats(C, x.device) if want_stats else None
-        H.call("ieagan_nchw_to_nhwc", x.data_ptr(), out.data_ptr(), H.ptr(stats), N, C, Hh * Ww, H.stream())
+        stats = new_stats(C, x.device, events) if want_stats else None
+        H.call("ieagan_nchw_to_nhwc", x.data_ptr(), out.data_ptr(), H.ptr(stats), N, C, Hh * Ww, N // events, H.stream())
+        ctx.events = events
         ctx.save_for_backward(out if want_stats else None)
         return out, stats
 
@@ -742,12 +759,12 @@ class ToNHWCFn(torch.autograd.Function):
         N, Hh, Ww, C = g.shape
         if dstats is not None:
             geff = torch.empty_like(g)
-            H.call("ieagan_effgrad", g.data_ptr(), out.data_ptr(), dstats[0].contiguous().data_ptr(), geff.data_ptr(), None,
-                   N * Hh * Ww, C, H.stream())
+            H.call("ieagan_effgrad", g.data_ptr(), out.data_ptr(), dstats[:, 0].contiguous().data_ptr(), geff.data_ptr(), None,
+                   N * Hh * Ww, C, ctx.events, H.stream())
             g = geff
         dx = torch.empty(N, C, Hh, Ww, dtype=torch.float32, device=g.device)
         H.call("ieagan_nhwc_to_nchw", g.data_ptr(), dx.data_ptr(), N, C, Hh * Ww, H.stream())
-        return dx, None
+        return dx, None, None
 
 
 class ToNCHWFn(torch.autograd.Function):
@@ -764,14 +781,14 @@ class ToNCHWFn(torch.autograd.Function):
     def backward(ctx, g):
         N, C, Hh, Ww = g.shape
         dx = torch.empty(N, Hh, Ww, C, dtype=BF16, device=g.device)
-        H.call("ieagan_nchw_to_nhwc", g.contiguous().float().data_ptr(), dx.data_ptr(), None, N, C, Hh * Ww, H.stream())
+        H.call("ieagan_nchw_to_nhwc", g.contiguous().float().data_ptr(), dx.data_ptr(), None, N, C, Hh * Ww, 0, H.stream())
         return dx
 
 
 def channel_stats(x: torch.Tensor) -> torch.Tensor:
     """(sum, sumsq) of a bf16 NHWC tensor (no autograd; for tensors not produced by a conv)."""
     C = x.shape[-1]
-    st = new_stats(C, x.device)
+    st = new_stats(C, x.device)[0]
     H.call("ieagan_channel_stats", x.data_ptr(), st.data_ptr(), x.numel() // C, C, H.stream())
     return st
 

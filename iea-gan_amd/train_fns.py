@@ -9,6 +9,11 @@ places where the reference raises: loss terms that are switched off are reported
 UnboundLocalError (9-Q2), and consistency regularisation with ``split_D`` runs a third discriminator pass on
 the augmented real event (9-Q3).  The five losses are read back with ONE host synchronisation.
 
+``config['events_per_step']`` = E > 1 (BASELINE configs[3]; the reference consumes exactly one event per step, SURVEY
+9-Q5): ``x`` / ``y`` hold E events of ``batch_size`` sensors, batched on the leading dimension through every kernel --
+BatchNorm statistics, the RRM tokens and the loss Grams stay per event, gradients are the mean over the events, the
+BatchNorm running statistics receive the mean of the E per-event momentum updates.
+
 Execution modes
 * eager: every launch issued from Python (reference behaviour, needed for explicit-noise parity tests);
 * ``config['hip_graph']``, one GPU: the WHOLE step is captured once and replayed as one HIP graph;
@@ -99,6 +104,11 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
     if config["pos_collected_numerator"]:
         raise NotImplementedError("pos_collected_numerator=True is not part of the MI355X path (reference default: False)")
     bs = config["batch_size"]
+    E = max(int(config.get("events_per_step", 1) or 1), 1)
+    if E > 1 and not (config["split_D"] and config["num_D_accumulations"] == 1 and config["num_G_accumulations"] == 1):
+        raise NotImplementedError("events_per_step > 1 needs split_D and no gradient accumulation: the E events of a step are "
+                                  "batched on the leading dimension (per-event BatchNorm / RRM / loss Grams), see DESIGN section 7")
+    chunk = bs * E                  # images one pass consumes: E events of batch_size sensors each
     contra = config["conditional_strategy"] == "Contra"
     t = 1.0
     sync = parallel.get_context()
@@ -108,16 +118,39 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
         G.register_forward_pre_hook(lambda m, inp: sync.wait("G"))
     st = {"x": None, "y": None, "noise": None, "emb_real": None, "counter": 0}     # state shared by the phases
 
+    def explicit(key):
+        """Explicit draws of a parity test: one dict per step, or a list of E per-event dicts (concatenated in event order)."""
+        noise = st["noise"]
+        if isinstance(noise, (list, tuple)):
+            vals = [n[key] for n in noise]
+            if isinstance(vals[0], dict):
+                return {k: torch.cat([v[k] for v in vals]) for k in vals[0]}
+            return torch.cat(vals)
+        return noise[key]
+
     def sample(phase):
         import diff_aug as _da
-        noise = st["noise"]
-        if noise is None:
+        if st["noise"] is None:
             z_.sample_()
             return
-        z_.copy_(noise["z_" + phase].to(z_.device))
-        G.__dict__["_next_rdof"] = noise["rdof_" + phase].to(z_.device)
+        z_.copy_(explicit("z_" + phase).to(z_.device))
+        G.__dict__["_next_rdof"] = explicit("rdof_" + phase).to(z_.device)
         if config["diff_aug"]:
-            _da.NEXT_DRAWS.append(noise["aug_" + phase])
+            _da.NEXT_DRAWS.append(explicit("aug_" + phase))
+
+    def per_event(**kw):
+        """The fused loss block evaluated per event (the contrastive / uniformity / IEA Grams are intra-event) and averaged:
+        (total, terms).  One launch per event; E = 1 is the plain call."""
+        if E == 1:
+            return ops.loss_block(**kw)
+        tensors = {k: v for k, v in kw.items() if torch.is_tensor(v)}
+        rest = {k: v for k, v in kw.items() if not torch.is_tensor(v)}
+        total = terms = None
+        for e in range(E):
+            tt, tm = ops.loss_block(**{k: v[e * bs:(e + 1) * bs] for k, v in tensors.items()}, **rest)
+            total = tt if total is None else total + tt
+            terms = tm if terms is None else terms + tm
+        return total / float(E), terms / float(E)
 
     # ------------------------------------------------------------------------------------------------ D phase
     def d_forward_backward():
@@ -125,9 +158,11 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
         x, y = st["x"], st["y"]
         G.optim.zero_grad()
         D.optim.zero_grad()
-        x_aug = CR_DiffAug(x) if config["Con_reg"] else None
-        xs, ys = torch.split(x, bs), torch.split(y, bs)
-        xa = torch.split(x_aug, bs) if x_aug is not None else None
+        x_aug = None
+        if config["Con_reg"]:
+            x_aug = CR_DiffAug(x, draws=explicit("cr") if st["noise"] is not None else None)
+        xs, ys = torch.split(x, chunk), torch.split(y, chunk)
+        xa = torch.split(x_aug, chunk) if x_aug is not None else None
         c = st["counter"] = 0
         zero = torch.zeros((), device=x.device)
         if config["toggle_grads"]:
@@ -137,7 +172,7 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
         for _ in range(config["num_D_accumulations"]):
             sample("d")
             joint_aug = config["Con_reg"] and not config["split_D"]
-            outs = GD(z_[:bs], ys[c], xs[c], ys[c], xa[c] if joint_aug else None, contra=contra, train_G=False,
+            outs = GD(z_[:chunk], ys[c], xs[c], ys[c], xa[c] if joint_aug else None, contra=contra, train_G=False,
                       split_D=config["split_D"], diff_aug=config["diff_aug"])
             aug_out = None
             if contra:
@@ -161,10 +196,10 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
             # every D-phase loss term in ONE fused launch (value + gradient): hinge real / fake, 2C, uniformity
             use_c = contra and config["contra_lambda"] != 0
             use_u = contra and bool(config["Uniformity_loss"])
-            D_loss, terms = ops.loss_block(dfake=D_fake, dreal=D_real, e=emb_real if (use_c or use_u) else None,
-                                           p=proxy_real if use_c else None, w_hinge_real=1.0, w_hinge_fake=1.0,
-                                           w_contra=config["contra_lambda"] if use_c else 0.0,
-                                           w_unif=config["unif_lambda"] if use_u else 0.0, temperature=t)
+            D_loss, terms = per_event(dfake=D_fake, dreal=D_real, e=emb_real if (use_c or use_u) else None,
+                                      p=proxy_real if use_c else None, w_hinge_real=1.0, w_hinge_fake=1.0,
+                                      w_contra=config["contra_lambda"] if use_c else 0.0,
+                                      w_unif=config["unif_lambda"] if use_u else 0.0, temperature=t)
             D_loss_real, D_loss_fake = terms[1], terms[2]
             if use_u:
                 unif_loss_d = terms[5]
@@ -187,7 +222,7 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
     # ------------------------------------------------------------------------------------------------ G phase
     def g_forward_backward():
         """train_fns.py:142-182; returns [G_loss, iea]."""
-        ys = torch.split(st["y"], bs)
+        ys = torch.split(st["y"], chunk)
         zero = torch.zeros((), device=st["y"].device)
         if config["toggle_grads"]:
             utils.toggle_grad(D, False)
@@ -204,11 +239,11 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
                 use_i = bool(config["IEA_loss"])
                 use_u = use_i and bool(config["Uniformity_loss"])      # nested under IEA_loss, as in the reference (:171-178)
                 need_e = use_c or use_i or use_u
-                G_loss, terms = ops.loss_block(dfake=D_fake, e=emb_fake if need_e else None, p=proxy_fake if use_c else None,
-                                               er=st["emb_real"] if use_i else None, w_hinge_gen=1.0,
-                                               w_contra=config["contra_lambda"] if use_c else 0.0,
-                                               w_unif=config["unif_lambda"] if use_u else 0.0,
-                                               w_iea=config["IEA_lambda"] if use_i else 0.0, temperature=t)
+                G_loss, terms = per_event(dfake=D_fake, e=emb_fake if need_e else None, p=proxy_fake if use_c else None,
+                                          er=st["emb_real"] if use_i else None, w_hinge_gen=1.0,
+                                          w_contra=config["contra_lambda"] if use_c else 0.0,
+                                          w_unif=config["unif_lambda"] if use_u else 0.0,
+                                          w_iea=config["IEA_lambda"] if use_i else 0.0, temperature=t)
                 if use_i:
                     iea_loss = terms[6]
             else:

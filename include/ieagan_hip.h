@@ -19,7 +19,7 @@ extern "C" {
 #endif
 
 const char* ieagan_last_error(void);
-#define IEAGAN_ABI_VERSION 2        /* bumped whenever a struct layout or a signature in this header changes */
+#define IEAGAN_ABI_VERSION 3        /* bumped whenever a struct layout or a signature in this header changes */
 int ieagan_abi_version(void);        /* == IEAGAN_ABI_VERSION of the header the library was built from */
 
 /* ---- profiling hooks (bench.py): per-kernel HIP-event timing on the launch stream ---- */
@@ -61,10 +61,13 @@ typedef struct {
     int Crb;
     const void* mask;     /* bf16 [N,H,W,Cout]: output zeroed where mask <= 0, or NULL          */
     void* out;            /* bf16 [N,H,W,Cout]                                                  */
-    float* stats;         /* fp32 [32][2][Cout] replicated (sum, sumsq), accumulated; or NULL   */
+    float* stats;         /* fp32 [E][32][2][Cout] replicated (sum, sumsq) per event, accumulated; or NULL */
+    int n_per_event;      /* images per event: E = N / n_per_event statistics groups (BatchNorm statistics are
+                           * intra-event); 0 or N = one event.  E > 1 needs n_per_event*H*W % 128 == 0 */
+    int flags;            /* IEAGAN_CONV_FORCE_GATHER: route a 3x3 layer through the gather kernel (tests)    */
 } ieagan_conv_desc;
+#define IEAGAN_CONV_FORCE_GATHER 1
 int ieagan_conv_forward(const ieagan_conv_desc* d, void* stream);
-int ieagan_conv_force_gather(int on);   /* tests: route 3x3 layers through the gather kernel   */
 
 /* ---- weight gradient: dWp[Cout][Kpad] += G^T A   (autograd of F.conv2d w.r.t. weight) -------- */
 typedef struct {
@@ -81,26 +84,32 @@ typedef struct {
 int ieagan_conv_wgrad(const ieagan_wgrad_desc* d, int use_tr_read, void* stream);
 
 /* ---- element-wise companions (bn_elem.hip) ---------------------------------------------------- */
-/* g_eff = dout + dsum[c] + 2*out*dsumsq[c]; colsum[32][C] += column sums (bias gradient).
- * Autograd of F.batch_norm's batch statistics folded into the producer's out-grad. */
+/* g_eff = dout + dsum[e][c] + 2*out*dsumsq[e][c]; colsum[32][C] += column sums (bias gradient).
+ * Autograd of F.batch_norm's batch statistics folded into the producer's out-grad.  P pixels in E events of P / E
+ * consecutive pixels each, dstat fp32 [E][2][C]. */
 int ieagan_effgrad(const void* dout, const void* out, const float* dstat, void* geff, float* colsum,
-                   long P, int C, void* stream);
+                   long P, int C, int E, void* stream);
 /* backward of the fused prologue: dx, and per-(n,c) d scale / d shift (atomically accumulated).
  * radd (optional): gradient of a shortcut that read the same x (channels [0,Ca) of a tensor with Cr
  * channels; rmode 0 same resolution, 1 = 2x2 sum of a tensor at double resolution), added into dx. */
 int ieagan_prologue_bwd(const void* da, const void* x, int Cx, const float* scale, const float* shift,
                         int nstride, int relu, int rs, void* dx, float* dscale, float* dshift,
                         int N, int Hs, int Ws, int C, const void* radd, int Cr, int Ca, int rmode, void* stream);
-/* ccbn / bn statistics -> scale/shift (+ running-stat update), layers.py:656-689, 728-742 */
+/* ccbn / bn statistics -> scale/shift (+ running-stat update), layers.py:656-689, 728-742.
+ * E events of N / E images: stats [E][32][2][C] (count = elements per channel of ONE event), mean_rstd [E][2][C],
+ * dstat [E][2][C]; the running statistics receive the mean of the E per-event momentum updates.  ld == 0 (plain bn):
+ * per-channel gain / bias; scale / shift then have rows = 1 for E == 1 and rows = N (one per image) for E > 1, and
+ * dgain / dbias are summed over the rows. */
 int ieagan_bn_finalize_fwd(const float* stats, float count, const float* gain, const float* bias, int ld,
                            int plus_one, float eps, float momentum, int training, float* run_mean,
-                           float* run_var, float* scale, float* shift, float* mean_rstd, int N, int C,
+                           float* run_var, float* scale, float* shift, float* mean_rstd, int N, int C, int E,
                            void* stream);
 int ieagan_bn_finalize_bwd(const float* dscale, const float* dshift, const float* gain, int ld, int plus_one,
                            const float* mean_rstd, float count, int training, float* dgain, float* dbias,
-                           int ldd, float* dstat, int N, int C, void* stream);
+                           int ldd, float* dstat, int N, int C, int E, void* stream);
 int ieagan_res_bwd(const void* g, int Cg, void* dr, int Cr, int Ca, int mode, int N, int Hr, int Wr, void* stream);
-int ieagan_nchw_to_nhwc(const float* in, void* out, float* stats, int N, int C, int HW, void* stream);
+/* stats (optional): fp32 [E][32][2][C] per-event replicated (sum, sumsq), E = N / n_per_event (0: one event) */
+int ieagan_nchw_to_nhwc(const float* in, void* out, float* stats, int N, int C, int HW, int n_per_event, void* stream);
 int ieagan_nhwc_to_nchw(const void* in, float* out, int N, int C, int HW, void* stream);
 int ieagan_channel_stats(const void* x, float* stats, long P, int C, void* stream);
 

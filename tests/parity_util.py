@@ -89,45 +89,94 @@ TOL = {"G_rel_l2": 5e-2, "D_out_rel_l2": 5e-2, "D_embed_rel_l2": 3e-2, "D_proxy_
        "grad_cos": 0.97}
 
 
-def step_parity(resolution=64, H_base=1, device="cuda:0", verbose=False, **cfg_over):
-    """One full train(x, y) (finite clip_norm so that G steps) on the HIP path vs the oracle:
-    the 5 losses, and the cosine between the flat G / D gradients."""
+def _flat_grads(net, grads):
+    ar = net._arena
+    f = torch.zeros(ar.n_param)
+    names = [k for k, _ in net.named_parameters()]
+    for (p, o, cnt), k in zip(ar.param_slices, names):
+        f[o:o + cnt] = grads[k].reshape(-1)
+    return f
+
+
+def step_parity(resolution=64, H_base=1, device="cuda:0", verbose=False, n=40, events=1, state_check=False, oracle_bf16=False,
+                inputs=None, **cfg_over):
+    """One full train(x, y) on the HIP path vs the oracle on identical weights / noise: the 5 losses and the flat G / D
+    gradients (cosine, rel-L2); with ``state_check`` also the post-step state (parameters after Adam, spectral-norm
+    ``u0`` / ``sv0``, BatchNorm running statistics).  ``n`` < 40 runs a sub-event of the first n sensors (full
+    256x768 resolution stays affordable for the CPU oracle), ``events`` > 1 the E-events-per-step path (configs[3]).
+    ``oracle_bf16``: additionally run the oracle with bf16-rounded conv operands / outputs (``O.ROUND_BF16``) and report
+    how far THAT moves the same quantities -- the rounding-noise floor the tolerances are stated against."""
     import model
     import train_fns
     import utils
-    cfg = make_cfg(resolution=resolution, H_base=H_base, clip_norm=1e9, **cfg_over)
-    n, hh, ww = 40, resolution, resolution * H_base
+    over = dict(clip_norm=1e9)
+    over.update(cfg_over)
+    cfg = make_cfg(resolution=resolution, H_base=H_base, batch_size=n, events_per_step=events, **over)
+    hh, ww = resolution, resolution * H_base
     g_state, d_state = O.synth_nets(cfg, 101, 202)
     G, D = build_product(cfg, g_state, d_state, device)
     GD = model.G_D(G, D)
-    z_, y_ = utils.prepare_z_y(n, G.dim_z, cfg["n_classes"], device=device)
+    z_, y_ = utils.prepare_z_y(n * events, G.dim_z, cfg["n_classes"], device=device)
     train = train_fns.GAN_training_function(G, D, GD, z_, y_, None, {"itr": 1}, cfg, device)
-    x = O.synth_event(n, hh, ww, 303)
     y = torch.arange(n)
-    noise = make_noise(n, hh, ww, 909)
-    out = train(x.to(device), y.to(device), noise=noise)
+    if inputs is not None:              # events + draws of a committed fixture
+        xs, noises = inputs
+    else:
+        xs = [O.synth_event(n, hh, ww, 303 + e) for e in range(events)]
+        noises = [make_noise(n, hh, ww, 909 + e) for e in range(events)]
+        if cfg.get("Con_reg"):
+            for e, nz in enumerate(noises):
+                nz["cr"] = O.cr_draws(n, hh, ww, generator=torch.Generator().manual_seed(77 + e))
+    if events == 1:
+        out = train(xs[0].to(device), y.to(device), noise=noises[0])
+    else:
+        out = train(torch.cat(xs).to(device), y.repeat(events).to(device), noise=noises)
     torch.cuda.synchronize()
     g_grad = G._arena.grad.clone().cpu()
     d_grad = D._arena.grad.clone().cpu()
-    # oracle
-    gsd, gp = O.as_trainable(g_state)
-    dsd, dp = O.as_trainable(d_state)
-    ts = O.TrainState(gsd, dsd, gp, dp, cfg)
-    ref = O.train_step(ts, x, y, noise, itr=1)
-    og, od = ts.last_grads
 
-    def flat(net, grads):
-        ar = net._arena
-        f = torch.zeros(ar.n_param)
-        names = [k for k, _ in net.named_parameters()]
-        for (p, o, cnt), k in zip(ar.param_slices, names):
-            f[o:o + cnt] = grads[k].reshape(-1)
-        return f
-    og_f, od_f = flat(G, og), flat(D, od)
+    def run_oracle():
+        gsd, gp = O.as_trainable(g_state)
+        dsd, dp = O.as_trainable(d_state)
+        ts = O.TrainState(gsd, dsd, gp, dp, cfg)
+        ref = O.train_step_events(ts, xs, y, noises, itr=1)
+        og, od = ts.last_grads
+        return ref, _flat_grads(G, og), _flat_grads(D, od), gsd, dsd
+
+    ref, og_f, od_f, gsd, dsd = run_oracle()
     rep = {"losses": out, "ref_losses": ref, "G_grad_cos": cosine(g_grad, og_f), "D_grad_cos": cosine(d_grad, od_f),
            "G_grad_rel": rel_l2(g_grad, og_f), "D_grad_rel": rel_l2(d_grad, od_f)}
     ok = all(abs(out[k] - ref[k]) <= TOL["loss"] * max(1.0, abs(ref[k])) for k in ref)
     ok = ok and rep["G_grad_cos"] >= TOL["grad_cos"] and rep["D_grad_cos"] >= TOL["grad_cos"]
+    if state_check:
+        st = {}
+        for name, net, osd, init in (("G", G, gsd, g_state), ("D", D, dsd, d_state)):
+            sd = net.state_dict()
+            u = [k for k in sd if k.endswith(".u0")]
+            st[name + "_u0_rel_max"] = max(rel_l2(sd[k], osd[k]) for k in u)
+            st[name + "_sv0_rel_max"] = max(rel_l2(sd[k], osd[k]) for k in sd if k.endswith(".sv0"))
+            rs = [k for k in sd if k.endswith("stored_mean") or k.endswith("stored_var")]
+            if rs:
+                st[name + "_bn_running_rel_max"] = max(rel_l2(sd[k], osd[k]) for k in rs)
+            params = [k for k, _ in net.named_parameters()]
+            upd = torch.cat([(sd[k].detach().cpu() - init[k]).reshape(-1) for k in params])
+            upd_o = torch.cat([(osd[k].detach() - init[k]).reshape(-1) for k in params])
+            # beta1 = 0: the first Adam update is lr * g / (|g| + eps), i.e. ~lr * sign(g) -- sign agreement is the metric
+            big = upd_o.abs() > 0.5 * float(upd_o.abs().max())
+            st[name + "_update_cos"] = cosine(upd, upd_o)
+            st[name + "_update_sign_agree"] = float((torch.sign(upd[big]) == torch.sign(upd_o[big])).float().mean())
+            st[name + "_param_rel"] = rel_l2(torch.cat([sd[k].detach().cpu().reshape(-1) for k in params]),
+                                             torch.cat([osd[k].detach().reshape(-1) for k in params]))
+        rep["state"] = st
+    if oracle_bf16:
+        O.ROUND_BF16 = True
+        try:
+            ref_b, og_b, od_b, _, _ = run_oracle()
+        finally:
+            O.ROUND_BF16 = False
+        rep["bf16_floor"] = {"G_grad_rel": rel_l2(og_b, og_f), "D_grad_rel": rel_l2(od_b, od_f), "G_grad_cos": cosine(og_b, og_f),
+                             "D_grad_cos": cosine(od_b, od_f), "loss_rel": {k: abs(ref_b[k] - ref[k]) / max(1.0, abs(ref[k])) for k in ref},
+                             "hip_vs_bf16_oracle_G_grad_rel": rel_l2(g_grad, og_b), "hip_vs_bf16_oracle_D_grad_rel": rel_l2(d_grad, od_b)}
     rep["ok"] = bool(ok)
     if verbose:
         print(rep)

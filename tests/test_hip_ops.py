@@ -142,14 +142,12 @@ def test_halo_and_gather_kernels_agree(dev):
     w = (torch.randn(Cout, 9 * Cin, device=dev) / 17).to(BF)
     sc, sh = 1 + 0.3 * torch.randn(N, Cin, device=dev), 0.2 * torch.randn(N, Cin, device=dev)
     outs = []
-    for force in (0, 1):
-        _hip.call("ieagan_conv_force_gather", force)
+    for force in (0, _hip.CONV_FORCE_GATHER):      # per-call flag of the conv descriptor (no process-wide switch)
         out = torch.empty(N, Hh, Ww, Cout, device=dev, dtype=BF)
         st = ops.new_stats(Cout, dev)
         ops._conv_launch(x, Cin, Hh, Ww, 0, sc, sh, Cin, True, N, Hh, Ww, Cin, Cout, 9, 9 * Cin, w, None, None, 0, 0, 0, None, 0,
-                         None, out, st)
-        outs.append((out, st.sum(0)))
-    _hip.call("ieagan_conv_force_gather", 0)
+                         None, out, st, flags=force)
+        outs.append((out, st.sum((0, 1))))
     close(outs[0][0], outs[1][0], 4e-3, "halo vs gather out")
     close(outs[0][1], outs[1][1], 1e-3, "halo vs gather stats")
 
@@ -172,13 +170,12 @@ def test_specialised_halo_variants_agree_with_gather(dev, N, Hh, Ww, C):
     bias = 0.1 * torch.randn(C, device=dev)
     mask = torch.randn(N, Hh, Ww, C, device=dev).to(BF)
     outs = []
-    for force in (0, 1):
-        _hip.call("ieagan_conv_force_gather", force)
+    for force in (0, _hip.CONV_FORCE_GATHER):
         out = torch.empty(N, Hh, Ww, C, device=dev, dtype=BF)
         st = ops.new_stats(C, dev)
-        ops._conv_launch(x, C, Hh, Ww, 0, None, None, 0, True, N, Hh, Ww, C, C, 9, kpad, w, bias, None, 0, 0, 0, None, 0, mask, out, st)
-        outs.append((out, st.sum(0)))
-    _hip.call("ieagan_conv_force_gather", 0)
+        ops._conv_launch(x, C, Hh, Ww, 0, None, None, 0, True, N, Hh, Ww, C, C, 9, kpad, w, bias, None, 0, 0, 0, None, 0, mask, out, st,
+                         flags=force)
+        outs.append((out, st.sum((0, 1))))
     close(outs[0][0], outs[1][0], 4e-3, "halo vs gather out")
     close(outs[0][1], outs[1][1], 2e-3, "halo vs gather stats")
 
@@ -212,12 +209,35 @@ def conv_reference(x, W, u, bias, scale, shift, relu, rs, taps, ra, ra_mode, Ca,
     return out
 
 
-@pytest.mark.parametrize("case", CONV_CASES, ids=[f"c{i}" for i in range(len(CONV_CASES))])
+# The layers the benchmark spends its time in, at their production geometry (model.py:86-95, 573-582 with ch = 32), on a
+# few images: forward + dgrad (incl. effgrad / prologue_bwd) + wgrad of every specialised kernel variant against fp32
+# PyTorch -- not against another HIP kernel.   (N chosen so that the launcher takes the same variant as at N = 40.)
+PROD_CASES = [
+    # taps Cin Cout H    W    aff    relu  rs residual               stats  N
+    (9, 16, 16, 256, 768, True, True, 0, None, True, 2),             # G b11 conv3: C=16 persistent-prefetch halo, ccbn prologue
+    (9, 16, 16, 256, 768, False, True, 0, None, False, 2),           # D s0.0 conv2/3: bare-ReLU prologue, fused mask in dgrad
+    (9, 16, 16, 128, 384, True, True, 1, None, True, 2),             # G b11 conv2: upsampled source 128x384 -> 256x768
+    (9, 32, 32, 128, 384, True, True, 0, None, True, 3),             # G b9 conv3: C=32 prefetch variant
+    (9, 32, 32, 128, 384, False, True, 0, None, False, 3),           # D s1.0 conv2/3
+    (9, 64, 64, 64, 192, False, True, 0, None, False, 22),           # D s2.0: C=64 LDS-resident weights (>= 1024 tiles)
+    (9, 64, 64, 32, 96, True, True, 0, None, True, 6),               # G b5/b6: C=64 pipelined K loop
+    (9, 128, 128, 16, 48, True, True, 0, None, True, 8),             # G b3/b4, D s4.0: C=128
+    (1, 16, 32, 256, 768, True, True, 0, ("up", 64, 32), True, 2),   # G b11 conv4 + upsampled, channel-dropped shortcut
+    (1, 64, 16, 128, 384, True, True, 0, None, True, 2),             # G b10/b11 conv1
+    (1, 32, 16, 256, 768, False, False, 0, None, False, 2),          # D s0.0 conv1 (first block: no pre-activation)
+    (1, 16, 64, 128, 384, False, True, 2, ("pool+sc", 32, 32), False, 2),   # D s0.0 conv4: pooled source + concat shortcut
+    (1, 32, 32, 128, 384, False, False, 2, None, False, 2),          # D s0.0 conv_sc on the pooled block input
+    (1, 16, 64, 128, 384, False, True, 0, ("same", 64, 64), False, 3),      # D s0.1 conv4 + identity shortcut
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES + PROD_CASES,
+                         ids=[f"c{i}" for i in range(len(CONV_CASES))] + [f"prod{i}" for i in range(len(PROD_CASES))])
 def test_conv_forward_backward(dev, case):
     import ops
-    taps, Cin, Cout, Hs, Ws, aff, relu, rs, res, stats = case
+    taps, Cin, Cout, Hs, Ws, aff, relu, rs, res, stats = case[:10]
     torch.manual_seed(1)
-    N = 3
+    N = case[10] if len(case) > 10 else 3
     k = 3 if taps == 9 else 1
     x = r16(torch.randn(N, Cin, Hs, Ws, device=dev)).requires_grad_(True)
     W = (torch.randn(Cout, Cin, k, k, device=dev) / math.sqrt(Cin * taps)).requires_grad_(True)
@@ -263,10 +283,10 @@ def test_conv_forward_backward(dev, case):
     close(nchw(out), ref, 1.5e-2, "conv out")
     loss = (out.float() * nhwc(go).float()).sum()
     if stats:
-        ssum = st.sum(0)
+        ssum = st.sum((0, 1))
         close(ssum[0], ref.sum((0, 2, 3)), 2e-2, "stat sum")
         close(ssum[1], (ref * ref).sum((0, 2, 3)), 2e-2, "stat sumsq")
-        loss = loss + (st.sum(0) * dsum).sum()
+        loss = loss + (st.sum((0, 1)) * dsum).sum()
     leaves2 = [t for t in (xa, Wp, b2, sc2, sh2, ra2, rb2) if t is not None]
     grads = torch.autograd.grad(loss, leaves2)
     names = [n for n, t in zip(("x", "W", "bias", "scale", "shift", "ra", "rb"), (x, W, bias, scale, shift, ra, rb)) if t is not None]
