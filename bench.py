@@ -5,13 +5,21 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 Workload at every N: BASELINE configs[1] per GPU -- one event (40 sensors x 256x768, i.e. 250x768 padded)
-per step, bf16 activations, hinge loss only, RRM on; synthetic PXD-like events, seeded orthogonal weights.
+per step, bf16 activations, hinge loss only, RRM on; synthetic PXD-like events (a rotation of 4 different ones, so the
+losses stay in their non-saturated regime), seeded orthogonal weights.
 N > 1: events shard data-parallel (one per rank and step), gradients are all-reduced over RCCL
 (``parallel.py``); value = events all ranks processed / max-over-ranks wall time ("weak" scaling).
 
-One JSON line on stdout (rank 0).  ``roofline`` describes the kernel that dominates GPU time, timed with
-HIP events on the launch stream inside the timed region; ``cpu_baseline`` is the CPU oracle (a plain
-PyTorch restatement of the reference step, oracle/) timed on this host on a bounded sample.
+One JSON line on stdout (rank 0):
+* ``roofline``: the kernel family with the largest share of GPU time.  ``achieved`` = ALGORITHMIC bytes (or FLOPs) of its
+  launches -- the layer-granular figures of SURVEY 8d, ``tools/arch_calc.py``: conv bytes = 2 N (Hs Ws Cin + H W Cout) --
+  divided by their HIP-event time measured in this run on the launch stream; ``launcher_accounted`` repeats the fraction with
+  the bytes the launches really have to move (plus ReLU masks / shortcut operands); ``traffic`` = HBM bytes per launch from
+  the committed rocprofv3 PMC passes (NOT measured in this run: see ``traffic_source``).
+* ``families``: every family with its HBM and MFMA fractions.
+* ``cpu_baseline``: the CPU oracle (plain PyTorch restatement of the reference step, oracle/) timed on this host.
+* ``configs3`` (N = 1, unless --no-configs3): the same measurement for BASELINE configs[3] -- 4 events per GPU and step with
+  DiffAugment + CR_DiffAug consistency regularisation + uniformity loss.
 """
 import argparse
 import contextlib
@@ -19,11 +27,13 @@ import io
 import json
 import math
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "iea-gan_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 import numpy as np
 import torch
@@ -32,6 +42,7 @@ import torch.distributed as dist
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0         # HBM3E spec (6.3 TB/s measured achievable)
 STEP_GFLOP = 5328.8           # algorithmic work per event-step (SURVEY 8d / BASELINE.md section 3)
+PMC_FILES = ("r02_pmc_traffic.json", "r01_final_pmc_traffic.json")      # newest first
 
 
 def synth_event(n, h, w, seed):
@@ -43,27 +54,49 @@ def synth_event(n, h, w, seed):
     return torch.from_numpy((2.0 * img - 1.0).astype(np.float32))
 
 
-def bench_config():
+def bench_config(which=1):
     from defaults import default_config
     cfg = default_config()
-    # configs[1]: hinge loss only, RRM on.  clip_norm must be finite or the reference's control flow never
-    # steps G's optimiser -- a benchmark without the G update would skip real work.
-    cfg.update(device="cuda", contra_lambda=0.0, IEA_loss=False, Uniformity_loss=False, clip_norm=1e9)
+    # clip_norm must be finite or the reference's control flow never steps G's optimiser -- a benchmark without
+    # the G update would skip real work.
+    cfg.update(device="cuda", clip_norm=1e9)
+    if which == 1:      # configs[1]: hinge loss only, RRM on
+        cfg.update(contra_lambda=0.0, IEA_loss=False, Uniformity_loss=False)
+    else:               # configs[3]: 4 events/GPU, diff_aug + cr_diff_aug + uniformity loss (full default loss composition)
+        cfg.update(events_per_step=4, Con_reg=True, diff_aug=True, Uniformity_loss=True)
     return cfg
 
 
-def cpu_baseline(cfg, sensors=8, threads=None):
-    """The oracle's train step at full 256x768 resolution on `sensors` of the 40 sensors of one event
-    (BN / RRM / losses over that sub-event), scaled by 40/sensors: bounded to tens of seconds."""
+def physical_cores():
+    try:
+        pairs, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    pairs.add((phys, core))
+                phys = core = None
+        return len(pairs) or None
+    except OSError:
+        return None
+
+
+def cpu_baseline(cfg, mode="sub", threads=None):
+    """The oracle's train step at full 256x768 resolution on this host's cores.  ``full``: all 40 sensors, 1 warm-up + 1
+    timed step (minutes of CPU time and ~30 GB of host memory).  ``sub`` (default, bounded to tens of
+    seconds): the first 8 of the 40 sensors -- BatchNorm / RRM / losses over that sub-event -- one timed step, scaled
+    by 40 / 8 (the conv work, > 95 % of the CPU time, is linear in the sensor count)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ieagan_oracle as O
-    threads = threads or min(os.cpu_count() or 1, 32)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = threads or min(avail, 32)
     torch.set_num_threads(threads)
-    c = dict(cfg, device="cpu")
+    sensors = 40 if mode == "full" else 8
+    c = dict(cfg, device="cpu", events_per_step=1)
     g_state, d_state = O.synth_nets(c, 101, 202)
-    gsd, gp = O.as_trainable(g_state)
-    dsd, dp = O.as_trainable(d_state)
-    ts = O.TrainState(gsd, dsd, gp, dp, c)
     h, w = c["resolution"], c["resolution"] * c["H_base"]
     x = O.synth_event(sensors, h, w, 303)
     y = torch.arange(sensors)
@@ -73,44 +106,80 @@ def cpu_baseline(cfg, sensors=8, threads=None):
         noise["z_" + ph] = torch.randn(sensors, 128, generator=gen)
         noise["rdof_" + ph] = torch.randn(sensors, 4, generator=gen)
         noise["aug_" + ph] = O.diffaug_draws(sensors, h, w, generator=gen)
-    t0 = time.time()
-    O.train_step(ts, x, y, noise, itr=1)
-    dt = time.time() - t0
-    return {"value": 1.0 / (dt * 40.0 / sensors), "unit": "events/s", "cores": threads, "kind": "port",
-            "sample": f"one oracle train step (fp32, PyTorch CPU) at 256x768 on {sensors} of 40 sensors: {dt:.1f} s, "
-                      f"scaled x{40 // sensors} to a full event"}
+    times = []
+    for rep in range(2 if mode == "full" else 1):
+        gsd, gp = O.as_trainable(g_state)
+        dsd, dp = O.as_trainable(d_state)
+        ts = O.TrainState(gsd, dsd, gp, dp, c)
+        t0 = time.time()
+        O.train_step(ts, x, y, noise, itr=1)
+        times.append(time.time() - t0)
+    dt = times[-1]
+    sample = (f"one oracle train step (fp32, PyTorch CPU) at 256x768 on all 40 sensors after one warm-up step: {dt:.1f} s "
+              f"(warm-up {times[0]:.1f} s)" if mode == "full" else
+              f"one oracle train step (fp32, PyTorch CPU) at 256x768 on {sensors} of 40 sensors: {dt:.1f} s, "
+              f"scaled x{40 // sensors} to a full event")
+    return {"value": 1.0 / (dt * 40.0 / sensors), "unit": "events/s", "cores": threads, "kind": "port", "sample": sample,
+            "host_logical_cpus_available": avail, "host_physical_cores": physical_cores()}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP-event timing")
-    ap.add_argument("--resolution", type=int, default=256)
-    ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying a HIP graph")
-    ap.add_argument("--shape-tags", action="store_true", help="per-kernel timing split by layer shape (tuning aid)")
-    args = ap.parse_args()
+def pmc_families():
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, corrected as the guide says)."""
+    for name in PMC_FILES:
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            try:
+                d = json.load(open(path))
+                return d.get("families", {}), f"profiles/{name}" + (f" @ {d['git_head']}" if d.get("git_head") else "")
+            except Exception as e:         # a malformed file must not silently turn into 'no traffic figure'
+                print(f"bench: cannot read {path}: {e}", file=sys.stderr)
+    return {}, None
 
+
+def git_head():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
+    except Exception:
+        return None
+
+
+def roofline_of(r, total_ms, pmc, pmc_src):
+    """Roofline block of one kernel family record (bytes_min / flops = tools/arch_calc.py's layer-granular figures)."""
+    ridge = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)          # ~312 FLOP/B
+    sec = r["ms"] * 1e-3
+    bmin = r.get("bytes_min") or r["bytes"]
+    hbm = bmin / sec / 1e9 if bmin else None
+    hbm_l = r["bytes"] / sec / 1e9 if r["bytes"] else None
+    tf = r["flops"] / sec / 1e12 if r["flops"] else None
+    ai = r["flops"] / bmin if (r["flops"] and bmin) else None
+    mfma_bound = ai is not None and ai >= ridge
+    out = {"kernel": r["name"], "bound": "mfma" if mfma_bound else "hbm",
+           "achieved": tf if mfma_bound else hbm, "peak": PEAK_BF16_TFLOPS if mfma_bound else PEAK_HBM_GBS,
+           "unit": "TFLOP/s" if mfma_bound else "GB/s"}
+    out["frac"] = (out["achieved"] / out["peak"]) if out["achieved"] is not None else None
+    fam = pmc.get(r["name"].split(" ")[0])
+    out.update(traffic=fam["hbm_bytes_per_launch"] if fam else None,
+               traffic_source=(pmc_src + " (rocprofv3 --pmc passes of that build; not measured in this run)") if fam else None,
+               hbm_frac=hbm / PEAK_HBM_GBS if hbm else None, mfma_frac=tf / PEAK_BF16_TFLOPS if tf else None,
+               launcher_accounted={"GBs": hbm_l, "hbm_frac": hbm_l / PEAK_HBM_GBS if hbm_l else None,
+                                   "bytes_per_launch": r["bytes"] / max(r["launches"], 1)},
+               algorithmic_bytes_per_launch=bmin / max(r["launches"], 1),
+               algorithmic_flops_per_launch=r["flops"] / max(r["launches"], 1), launches=r["launches"],
+               avg_launch_ms=r["ms"] / max(r["launches"], 1), share_of_kernel_time=r["ms"] / total_ms,
+               arithmetic_intensity=ai)
+    return out
+
+
+def measure(cfg, args, rank, world, local, tag):
+    """Build the networks for ``cfg``, warm up, time ``args.steps`` steps, optionally time every kernel family."""
     import _hip
     import model
     import parallel
     import train_fns
     import utils
-
-    rank, world, local = parallel.init_from_env("nccl")
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    _hip.require_gpu()
-    torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    cfg = bench_config()
-    cfg["resolution"] = args.resolution
-    cfg["hip_graph"] = not args.no_graph
+    E = int(cfg.get("events_per_step", 1))
     force_dp = bool(os.environ.get("IEAGAN_FORCE_DP")) and dist.is_initialized()     # 1-rank rehearsal of the DP path
-    if args.resolution != 256:
-        cfg["H_base"] = 1
     utils.seed_rng(cfg["seed"])
     with contextlib.redirect_stdout(io.StringIO()):
         G = model.Generator(**cfg).to(dev)
@@ -123,17 +192,19 @@ def main():
         for net in (G, D):
             net._prepare()
             parallel.broadcast_flat(net._arena.flat)
-    z_, y_ = utils.prepare_z_y(40, G.dim_z, cfg["n_classes"], device=dev)
+        parallel.broadcast_flat(ema._arenas()[1].flat)
+    z_, y_ = utils.prepare_z_y(40 * E, G.dim_z, cfg["n_classes"], device=dev)
     state = {"itr": 0}
     train = train_fns.GAN_training_function(G, D, GD, z_, y_, ema, state, cfg, dev)
     h, w = cfg["resolution"], cfg["resolution"] * cfg["H_base"]
-    x = synth_event(40, h, w, cfg["seed"] + rank).to(dev)
-    y = torch.arange(40, device=dev)
+    n_rot = 4
+    xs = [torch.cat([synth_event(40, h, w, cfg["seed"] + 1000 * rank + 10 * i + e) for e in range(E)]).to(dev) for i in range(n_rot)]
+    y = torch.arange(40, device=dev).repeat(E)
     G.train(); D.train(); G_ema.train()
 
     def step():
         state["itr"] += 1
-        return train(x, y)
+        return train(xs[state["itr"] % n_rot], y)
 
     for _ in range(max(args.warmup, 3 if cfg["hip_graph"] else 0)):    # graph mode: 2 eager steps + capture
         step()
@@ -149,84 +220,142 @@ def main():
     if eager_timing:            # eager mode: HIP events bracket every launch inside the timed region itself
         _hip.call("ieagan_prof_reset")
         _hip.prof_enable(True)
+    steps = args.steps if tag == "configs1" else max(2, min(args.steps, 5))
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         out = step()
     fence()
     dt = time.perf_counter() - t0
     if eager_timing:
         _hip.prof_enable(False)
-    prof_steps = args.steps
+    prof_steps = steps
+    recs = None
     if timing and cfg["hip_graph"]:
         # A replayed HIP graph cannot carry per-launch event pairs: time the SAME launches (same shapes,
         # same kernels) in eager steps right after the timed region.
-        prof_steps = min(args.steps, 3)
+        prof_steps = min(steps, 3)
         _hip.call("ieagan_prof_reset")
         _hip.prof_enable(2 if args.shape_tags else 1)
         for _ in range(prof_steps):
             state["itr"] += 1
-            train.step_tensor(x, y)
+            train.step_tensor(xs[state["itr"] % n_rot], y)
         torch.cuda.synchronize()
         _hip.prof_enable(False)
+    if timing:
+        recs = sorted(_hip.prof_collect(), key=lambda r: -r["ms"])
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    parallel.set_context(None)
+    return dict(dt=dt, steps=steps, out=out, recs=recs, prof_steps=prof_steps, eager_timing=eager_timing, h=h, w=w, E=E)
+
+
+def kernel_report(res, m, args):
+    recs, prof_steps = m["recs"], m["prof_steps"]
+    total = sum(r["ms"] for r in recs) or 1.0
+    pmc, pmc_src = pmc_families()
+    res["roofline"] = roofline_of(recs[0], total, pmc, pmc_src)
+    ridge = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+    mf = [r for r in recs if r["flops"] > 0 and r["bytes"] and r["flops"] / (r.get("bytes_min") or r["bytes"]) >= ridge / 4]
+    if mf:
+        res["roofline_conv_mfma"] = dict(roofline_of(mf[0], total, pmc, pmc_src), bound="mfma", unit="TFLOP/s", peak=PEAK_BF16_TFLOPS,
+                                         achieved=mf[0]["flops"] / (mf[0]["ms"] * 1e-3) / 1e12,
+                                         frac=mf[0]["flops"] / (mf[0]["ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS)
+    fams = []
+    for r in recs[:(60 if args.shape_tags else 14)]:
+        sec = r["ms"] * 1e-3
+        bmin = r.get("bytes_min") or r["bytes"]
+        fams.append({"name": r["name"], "launches_per_step": r["launches"] / prof_steps, "ms_per_step": r["ms"] / prof_steps,
+                     "tflops": (r["flops"] / sec / 1e12) if r["flops"] else None, "GBs": (bmin / sec / 1e9) if bmin else None,
+                     "mfma_frac": (r["flops"] / sec / 1e12 / PEAK_BF16_TFLOPS) if r["flops"] else None,
+                     "hbm_frac": (bmin / sec / 1e9 / PEAK_HBM_GBS) if bmin else None,
+                     "algorithmic_gbytes_per_step": bmin / prof_steps / 1e9 if bmin else None,
+                     "launcher_gbytes_per_step": r["bytes"] / prof_steps / 1e9 if r["bytes"] else None})
+    res["families"] = fams
+    res["kernel_ms_per_step_total"] = total / prof_steps
+    res["launches_per_step"] = sum(r["launches"] for r in recs) / prof_steps
+    res["kernel_timing"] = ("HIP events around every launch inside the timed region" if m["eager_timing"] else
+                            f"HIP events around every launch in {prof_steps} eager steps run right after the timed graph replays")
+    if m["E"] == 1 and m["h"] == 256:
+        try:        # cross-check of the launchers' 8(d) byte accounting against the architecture calculator
+            import arch_calc
+            calc = arch_calc.step_family_gbytes()
+            got = {"conv1x1_fwd_dgrad": 0.0, "conv3x3_fwd_dgrad": 0.0, "conv1x1_wgrad": 0.0, "conv3x3_wgrad": 0.0}
+            for r in recs:
+                fam = r["name"].split(" ")[0]
+                key = {"conv1x1_gather": "conv1x1_fwd_dgrad", "conv3x3_halo": "conv3x3_fwd_dgrad", "conv3x3_gather": "conv3x3_fwd_dgrad",
+                       "conv1x1_wgrad": "conv1x1_wgrad", "conv3x3_wgrad": "conv3x3_wgrad"}.get(fam)
+                if key:
+                    got[key] += (r.get("bytes_min") or r["bytes"]) / prof_steps / 1e9
+            res["arch_calc_check"] = {k: {"calculator_gbytes": calc[k], "measured_launches_gbytes": got[k]} for k in calc}
+        except Exception as e:
+            res["arch_calc_check"] = f"unavailable: {e}"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", choices=("sub", "full"), default="sub",
+                    help="sub: 8 of 40 sensors x5 (tens of seconds); full: 40 sensors, 1 warm-up + 1 timed step (minutes, ~30 GB)")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-kernel HIP-event timing")
+    ap.add_argument("--no-configs3", action="store_true", help="skip the additional configs[3] (4 events/GPU + Con_reg) measurement")
+    ap.add_argument("--only-configs3", action="store_true", help="run configs[3] as the headline workload (tuning aid)")
+    ap.add_argument("--resolution", type=int, default=256)
+    ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying a HIP graph")
+    ap.add_argument("--shape-tags", action="store_true", help="per-kernel timing split by layer shape (tuning aid)")
+    args = ap.parse_args()
+
+    import _hip
+    import parallel
+
+    rank, world, local = parallel.init_from_env("nccl")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    _hip.require_gpu()
+    torch.cuda.set_device(local)
+
+    def cfg_for(which):
+        cfg = bench_config(which)
+        cfg["resolution"] = args.resolution
+        cfg["hip_graph"] = not args.no_graph
+        if args.resolution != 256:
+            cfg["H_base"] = 1
+        return cfg
+
+    cfg = cfg_for(3 if args.only_configs3 else 1)
+    m = measure(cfg, args, rank, world, local, "configs1")
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
-
-    res = {"metric": "events/sec (40x250x768) per G+D train step", "value": world * args.steps / dt, "unit": "events/s",
-           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+    E, h, w, dt, steps = m["E"], m["h"], m["w"], m["dt"], m["steps"]
+    desc1 = (f"BASELINE configs[1]: 1 event (40x1x{h}x{w}) per GPU per step, hinge loss only, RRM on, DiffAugment on, ortho reg + "
+             "Adam + EMA in the timed region, fp32 master weights, 4 synthetic events in rotation")
+    desc3 = (f"BASELINE configs[3]: 4 events (160x1x{h}x{w}) per GPU per step, DiffAugment + CR_DiffAug consistency regularisation "
+             "(third D pass) + contrastive + IEA + uniformity losses, RRM on")
+    res = {"metric": "events/sec (40x250x768) per G+D train step", "value": world * E * steps / dt, "unit": "events/s",
+           "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / steps,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-           "config": {"workload": f"BASELINE configs[1]: 1 event (40x1x{h}x{w}) per GPU per step, hinge loss only, RRM on, "
-                                  "DiffAugment on, ortho reg + Adam + EMA in the timed region, fp32 master weights",
-                      "events_per_gpu_per_step": 1, "parallelism": f"dp{world}", "clip_norm": cfg["clip_norm"],
-                      "hip_graph": bool(cfg["hip_graph"])},
-           "step_tflops_algorithmic": STEP_GFLOP * 1e-3 * world * args.steps / dt if args.resolution == 256 else None,
-           "losses_last_step": out}
-    if timing:
-        recs = sorted(_hip.prof_collect(), key=lambda r: -r["ms"])
-        total = sum(r["ms"] for r in recs) or 1.0
-        ridge = PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)          # ~312 FLOP/B
-        pmc = {}
-        try:      # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, corrected)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_final_pmc_traffic.json")))["families"]
-        except Exception:
-            pass
-
-        def roofline_of(r):
-            ai = r["flops"] / r["bytes"] if r["bytes"] else float("inf")
-            if r["flops"] > 0 and ai >= ridge / 4:      # near / above the ridge: price against the MFMA peak
-                ach = r["flops"] / (r["ms"] * 1e-3) / 1e12
-                out = {"kernel": r["name"], "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                       "frac": ach / PEAK_BF16_TFLOPS}
-            else:
-                ach = r["bytes"] / (r["ms"] * 1e-3) / 1e9
-                out = {"kernel": r["name"], "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                       "frac": ach / PEAK_HBM_GBS}
-            fam = pmc.get(r["name"].split(" ")[0])
-            out.update(traffic=fam["hbm_bytes_per_launch"] if fam else None,
-                       algorithmic_bytes_per_launch=r["bytes"] / max(r["launches"], 1),
-                       algorithmic_flops_per_launch=r["flops"] / max(r["launches"], 1), launches=r["launches"],
-                       avg_launch_ms=r["ms"] / max(r["launches"], 1), share_of_kernel_time=r["ms"] / total,
-                       arithmetic_intensity=ai if ai != float("inf") else None)
-            return out
-
-        res["roofline"] = roofline_of(recs[0])
-        mf = [r for r in recs if r["flops"] > 0 and r["bytes"] and r["flops"] / r["bytes"] >= ridge / 4]
-        if mf:
-            res["roofline_conv_mfma"] = roofline_of(mf[0])
-        res["kernels"] = [{"name": r["name"], "launches": r["launches"], "ms_per_step": r["ms"] / prof_steps,
-                           "tflops": (r["flops"] / (r["ms"] * 1e-3) / 1e12) if r["flops"] else None,
-                           "GBs": (r["bytes"] / (r["ms"] * 1e-3) / 1e9) if r["bytes"] else None} for r in recs[:(60 if args.shape_tags else 12)]]
-        res["kernel_ms_per_step_total"] = total / prof_steps
-        res["kernel_timing"] = ("HIP events around every launch inside the timed region" if eager_timing else
-                                f"HIP events around every launch in {prof_steps} eager steps run right after the timed graph replays")
+           "config": {"workload": desc3 if args.only_configs3 else desc1, "events_per_gpu_per_step": E,
+                      "parallelism": f"dp{world}", "clip_norm": cfg["clip_norm"], "hip_graph": bool(cfg["hip_graph"])},
+           "step_tflops_algorithmic": STEP_GFLOP * 1e-3 * world * steps / dt if (args.resolution == 256 and E == 1) else None,
+           "losses_last_step": m["out"], "git_head": git_head()}
+    if m["recs"]:
+        kernel_report(res, m, args)
+    if world == 1 and not args.no_configs3 and not args.only_configs3:
+        m3 = measure(cfg_for(3), args, rank, world, local, "configs3")
+        r3 = {"workload": desc3, "value": m3["E"] * m3["steps"] / m3["dt"], "unit": "events/s", "steps": m3["steps"],
+              "ms_per_step": 1e3 * m3["dt"] / m3["steps"], "events_per_gpu_per_step": m3["E"], "losses_last_step": m3["out"]}
+        if m3["recs"]:
+            kernel_report(r3, m3, args)
+        res["configs3"] = r3
     if world == 1 and not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(cfg)
+        res["cpu_baseline"] = cpu_baseline(cfg_for(1), args.cpu_baseline)
     print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

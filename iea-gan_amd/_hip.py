@@ -40,7 +40,7 @@ class WgradDesc(C.Structure):
 
 class ProfRec(C.Structure):
     _fields_ = [("name", C.c_char * 96), ("launches", C.c_long), ("ms", C.c_double),
-                ("flops", C.c_double), ("bytes", C.c_double)]
+                ("flops", C.c_double), ("bytes", C.c_double), ("bytes_min", C.c_double)]
 
 
 ABI_VERSION = 3            # include/ieagan_hip.h: IEAGAN_ABI_VERSION
@@ -147,4 +147,4 @@ def prof_collect() -> list:
     buf = (ProfRec * 512)()
     n = lib().ieagan_prof_collect(buf, 512)
     return [dict(name=buf[k].name.decode(), launches=buf[k].launches, ms=buf[k].ms, flops=buf[k].flops,
-                 bytes=buf[k].bytes) for k in range(n)]
+                 bytes=buf[k].bytes, bytes_min=buf[k].bytes_min) for k in range(n)]

@@ -29,7 +29,7 @@ extern "C" int ieagan_abi_version(void) { return IEAGAN_ABI_VERSION; }
 struct ProfEvt {
     std::string name;
     hipEvent_t a, b;
-    double flops, bytes;
+    double flops, bytes, bytes_min;
 };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
@@ -38,9 +38,9 @@ static std::vector<ProfEvt> g_prof;
 static bool g_prof_tags = false;
 bool prof_tags_on() { return g_prof_on && g_prof_tags; }
 
-ProfScope::ProfScope(const char* name, double flops, double bytes, hipStream_t s, const char* tag) : slot(-1), stream(s) {
+ProfScope::ProfScope(const char* name, double flops, double bytes, hipStream_t s, const char* tag, double bytes_min) : slot(-1), stream(s) {
     if (!g_prof_on) return;
-    ProfEvt e{std::string(name), nullptr, nullptr, flops, bytes};
+    ProfEvt e{std::string(name), nullptr, nullptr, flops, bytes, bytes_min < 0.0 ? bytes : bytes_min};
     if (g_prof_tags && tag != nullptr) e.name += std::string(" ") + tag;
     if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
     hipEventRecord(e.a, s);
@@ -92,6 +92,7 @@ extern "C" int ieagan_prof_collect(ieagan_prof_rec* out, int cap) {
         r.ms += ms;
         r.flops += e.flops;
         r.bytes += e.bytes;
+        r.bytes_min += e.bytes_min;
     }
     prof_clear_locked();
     int n = 0;

@@ -19,7 +19,7 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 void ieagan_set_error(const char* fmt, ...);
 // optional per-kernel event profiling (api.hip); name must be a string literal
 struct ProfScope {
-    ProfScope(const char* name, double flops, double bytes, hipStream_t s, const char* tag = nullptr);
+    ProfScope(const char* name, double flops, double bytes, hipStream_t s, const char* tag = nullptr, double bytes_min = -1.0);
     ~ProfScope();
     int slot;
     hipStream_t stream;

@@ -724,6 +724,7 @@ int conv_gather_launch(const ConvArgs& a, hipStream_t st) {
     const double flops = 2.0 * a.N * a.H * a.W * (double)a.Cout * a.taps * a.Cin;
     // algorithmic bytes: source + output + the epilogue operands (ReLU mask, residual slices at their own resolution)
     double bytes = 2.0 * a.N * ((double)a.src.Hs * a.src.Ws * a.Cin + (double)a.H * a.W * a.Cout);
+    const double bytes_min = bytes;      // SURVEY 8d / tools/arch_calc.py: source + output only
     if (a.mask) bytes += 2.0 * a.N * (double)a.H * a.W * a.Cout;
     if (a.ra) bytes += 2.0 * a.N * (double)a.H * a.W * a.Ca * (a.ra_rs == 1 ? 0.25 : (a.ra_rs == 2 ? 4.0 : 1.0));
     if (a.rb) bytes += 2.0 * a.N * (double)a.H * a.W * (a.Cout - a.Ca);
@@ -733,7 +734,7 @@ int conv_gather_launch(const ConvArgs& a, hipStream_t st) {
     if (prof_tags_on())
         snprintf(tag, sizeof(tag), "ci%d co%d %dx%d rs%d a%d r%d res%d%s", a.Cin, a.Cout, a.H, a.W, a.src.rs, a.src.scale != nullptr,
                  a.src.relu, a.ra ? a.ra_rs + 1 : 0, a.mask ? " mask" : "");
-    ProfScope prof(a.taps == 9 ? (halo ? "conv3x3_halo" : "conv3x3_gather") : "conv1x1_gather", flops, bytes, st, tag);
+    ProfScope prof(a.taps == 9 ? (halo ? "conv3x3_halo" : "conv3x3_gather") : "conv1x1_gather", flops, bytes, st, tag, bytes_min);
     int rc;
     if (halo) {
         rc = (a.src.rs == 0) ? launch_halo_pro<0>(a, st) : launch_halo_pro<1>(a, st);

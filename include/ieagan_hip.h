@@ -25,8 +25,11 @@ int ieagan_abi_version(void);        /* == IEAGAN_ABI_VERSION of the header the 
 /* ---- profiling hooks (bench.py): per-kernel HIP-event timing on the launch stream ---- */
 int ieagan_prof_enable(int on);          /* 0 off | 1 time every launch (hipEvents) | 2 + shape tags */
 int ieagan_prof_reset(void);
-/* Writes up to `cap` records {name[48], launches, ms, flops, bytes}; returns the record count.   */
-typedef struct { char name[96]; long launches; double ms; double flops; double bytes; } ieagan_prof_rec;
+/* Writes up to `cap` records; returns the record count.  `bytes` = what the launches had to move by the launcher's own
+ * accounting (operands incl. ReLU masks / shortcut tensors an epilogue really reads); `bytes_min` = the layer-granular
+ * minimum of SURVEY 8d (conv: 2 * N * (Hs*Ws*Cin + H*W*Cout), tools/arch_calc.py), equal to `bytes` where no such
+ * distinction exists. */
+typedef struct { char name[96]; long launches; double ms; double flops; double bytes; double bytes_min; } ieagan_prof_rec;
 int ieagan_prof_collect(ieagan_prof_rec* out, int cap);
 
 /* ---- source operand of a convolution with its fused prologue --------------------------------
