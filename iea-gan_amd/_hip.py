@@ -29,7 +29,8 @@ class ConvDesc(C.Structure):
     _fields_ = [("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
                 ("taps", C.c_int), ("Kpad", C.c_int), ("src", SrcDesc), ("w", vp), ("bias", vp),
                 ("ra", vp), ("Cra", C.c_int), ("Ca", C.c_int), ("ra_rs", C.c_int), ("ra_scale", C.c_float), ("rb", vp),
-                ("Crb", C.c_int), ("mask", vp), ("out", vp), ("stats", vp), ("n_per_event", C.c_int), ("flags", C.c_int)]
+                ("Crb", C.c_int), ("mask", vp), ("out", vp), ("stats", vp), ("n_per_event", C.c_int), ("flags", C.c_int),
+                ("bnb_scale", vp), ("bnb_shift", vp), ("bnb_nstride", C.c_int), ("bnb_relu", C.c_int)]
 
 
 class WgradDesc(C.Structure):
@@ -43,7 +44,7 @@ class ProfRec(C.Structure):
                 ("flops", C.c_double), ("bytes", C.c_double), ("bytes_min", C.c_double)]
 
 
-ABI_VERSION = 3            # include/ieagan_hip.h: IEAGAN_ABI_VERSION
+ABI_VERSION = 4            # include/ieagan_hip.h: IEAGAN_ABI_VERSION
 i, f, l = C.c_int, C.c_float, C.c_long
 _SIGS = {
     "ieagan_abi_version": [],
@@ -55,7 +56,7 @@ _SIGS = {
     "ieagan_effgrad": [vp, vp, vp, vp, vp, l, i, i, vp],
     "ieagan_prologue_bwd": [vp, vp, i, vp, vp, i, i, i, vp, vp, vp, i, i, i, i, vp, i, i, i, vp],
     "ieagan_bn_finalize_fwd": [vp, f, vp, vp, i, i, f, f, i, vp, vp, vp, vp, vp, i, i, i, vp],
-    "ieagan_bn_finalize_bwd": [vp, vp, vp, i, i, vp, f, i, vp, vp, i, vp, i, i, i, vp],
+    "ieagan_bn_finalize_bwd": [vp, vp, vp, i, i, vp, f, i, vp, vp, i, vp, i, i, i, i, vp],
     "ieagan_res_bwd": [vp, i, vp, i, i, i, i, i, i, vp],
     "ieagan_nchw_to_nhwc": [vp, vp, vp, i, i, i, i, vp],
     "ieagan_nhwc_to_nchw": [vp, vp, i, i, i, vp],

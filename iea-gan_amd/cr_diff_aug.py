@@ -2,7 +2,7 @@
 by a reflect-padded translation of up to 1/8 of each side -- one gather kernel.
 
 Surface of reference ``cr_diff_aug.py`` (``CR_DiffAug(x, flip, translation)``).  Draw order as the
-reference: a CPU uniform [N,1] for the flip, then ``randint`` t_x and t_y on ``x.device``.
+reference: a uniform [N,1] for the flip, then ``randint`` t_x and t_y, all on ``x.device``.
 """
 from __future__ import annotations
 
@@ -13,7 +13,10 @@ import ops
 
 
 def draw(n, h, w, device, generator=None):
-    d = {"flip": torch.rand(n, 1, generator=generator if (generator is None or generator.device.type == "cpu") else None)}
+    # The reference draws the flip uniforms from the CPU generator (cr_diff_aug.py:24) and copies them over; here all three draws
+    # come from the generator of ``device``: no host-to-device copy inside the step (a captured HIP graph cannot contain one),
+    # same distribution.  Bit-level replay of the reference's stream is the job of the explicit ``draws`` argument.
+    d = {"flip": torch.rand(n, 1, device=device, generator=generator)}
     d["tx"] = torch.randint(-int(h / 8), int(h / 8) + 1, size=[n, 1, 1], device=device, generator=generator)
     d["ty"] = torch.randint(-int(w / 8), int(w / 8) + 1, size=[n, 1, 1], device=device, generator=generator)
     return d

@@ -295,12 +295,12 @@ extern "C" int ieagan_bn_finalize_fwd(const float* stats, float count, const flo
 __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* __restrict__ dscale, const float* __restrict__ dshift,
                                        const float* __restrict__ gain, int ld, int plus_one, const float* __restrict__ mean_rstd,
                                        float count, int training, float* __restrict__ dgain, float* __restrict__ dbias, int ldd,
-                                       float* __restrict__ dstat, int N, int C, int E) {
+                                       float* __restrict__ dstat, int N, int C, int E, int R) {
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
     const int npe = N / E;
-    const int rows = (ld == 0 && E == 1) ? 1 : N;
+    const int rows = (ld == 0 && E == 1 && R == 0) ? 1 : N;
     float dg_sum = 0.f, db_sum = 0.f;            // ld == 0: per-channel parameters, summed over rows / events
     for (int e = 0; e < E; ++e) {
         const float mean = mean_rstd[(long)e * 2 * C + c], rstd = mean_rstd[(long)e * 2 * C + C + c];
@@ -308,7 +308,18 @@ __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* __res
         const int n0 = (rows == 1) ? 0 : e * npe, n1 = (rows == 1) ? 1 : (e + 1) * npe;
         for (int n = n0 + lane; n < n1; n += 64) {
             const float g = gain[(long)n * ld + c] + (plus_one ? 1.f : 0.f);
-            const float ds = dscale[(long)n * C + c], dt = dshift[(long)n * C + c];
+            float ds, dt;
+            if (R > 0) {                             // replicated per-image accumulators of a BatchNorm-backward dgrad launch
+                ds = dt = 0.f;
+                const float* acc = dscale + (long)n * R * 2 * C;
+                for (int r = 0; r < R; ++r) {
+                    dt += acc[(long)r * 2 * C + c];
+                    ds += acc[(long)r * 2 * C + C + c];
+                }
+            } else {
+                ds = dscale[(long)n * C + c];
+                dt = dshift[(long)n * C + c];
+            }
             const float ee = ds - dt * mean;          // d/d(scale) with shift = bias - mean*scale folded in
             if (ld != 0) {
                 dgain[(long)n * ldd + c] = ee * rstd;
@@ -346,13 +357,14 @@ __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* __res
 
 extern "C" int ieagan_bn_finalize_bwd(const float* dscale, const float* dshift, const float* gain, int ld, int plus_one,
                                       const float* mean_rstd, float count, int training, float* dgain, float* dbias,
-                                      int ldd, float* dstat, int N, int C, int E, void* stream) {
+                                      int ldd, float* dstat, int N, int C, int E, int acc_repl, void* stream) {
     if (E < 1) E = 1;
     CHECK_ARG(N % E == 0, "bn_finalize_bwd: %d images are not %d whole events", N, E);
+    CHECK_ARG(acc_repl >= 0 && acc_repl <= 64, "bn_finalize_bwd: bad replica count %d", acc_repl);
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof("bn_finalize_bwd", 0.0, 0.0, st);
     hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, dscale, dshift, gain, ld, plus_one,
-                       mean_rstd, count, training, dgain, dbias, ldd, dstat, N, C, E);
+                       mean_rstd, count, training, dgain, dbias, ldd, dstat, N, C, E, acc_repl);
     CHECK_LAUNCH("bn_finalize_bwd");
     return 0;
 }

@@ -14,6 +14,7 @@
 // D[row 4*(l>>4)+r][col l&15].
 #include "common.h"
 #include "conv_args.h"
+#include "conv_common.h"
 #include <stdio.h>
 
 // ------------------------------------------------------------------------------------------------
@@ -21,37 +22,6 @@
 // conv-input pixel (n, hh, ww) at conv resolution; zero outside the image (conv padding is applied
 // AFTER the activation, as in the reference where the activated tensor is what gets padded).
 // ------------------------------------------------------------------------------------------------
-// Per-(n, c) scale / shift of the fused BatchNorm apply.  `aff` (optional) is a block-resident LDS copy of image n's rows,
-// [0, AFF_MAXC) scale and [AFF_MAXC, 2*AFF_MAXC) shift: the table is 64 bytes per 16 bytes of activation when fetched
-// through the vector-memory path, which made the affine variants address-unit bound.
-#define AFF_MAXC 512
-__device__ __forceinline__ void stage_aff(float* aff, const SrcDesc& s, int n, int Cin) {
-    for (int i = threadIdx.x; i < Cin; i += 256) {
-        aff[i] = s.scale[(long)n * s.aff_nstride + i];
-        aff[AFF_MAXC + i] = s.shift[(long)n * s.aff_nstride + i];
-    }
-}
-
-template <bool AFF, bool RELU>
-__device__ __forceinline__ void xform8(float (&v)[8], const SrcDesc& s, int n, int c, const float* aff = nullptr) {
-    if (AFF) {
-        f32x8 sc, sh;
-        if (aff != nullptr) {
-            sc = *(const f32x8*)(aff + c);
-            sh = *(const f32x8*)(aff + AFF_MAXC + c);
-        } else {
-            sc = *(const f32x8*)(s.scale + (long)n * s.aff_nstride + c);
-            sh = *(const f32x8*)(s.shift + (long)n * s.aff_nstride + c);
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = v[i] * sc[i] + sh[i];
-    }
-    if (RELU) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.f);
-    }
-}
-
 template <bool AFF, bool RELU, int RS>
 __device__ __forceinline__ bf16x8 gather8(const SrcDesc& s, int H, int W, int n, int hh, int ww, int c, bool ok,
                                           const float* aff = nullptr) {
@@ -103,7 +73,9 @@ struct EpiLds {
     static constexpr int FLOATS = 32 * LDW;
 };
 
-template <int NT, int MTS = 2, typename PixFn>
+// BNBOK: the BatchNorm-backward epilogue mode (ieagan_conv_desc.bnb_*) is compiled in -- only for the plain-prologue variants,
+// which is what a dgrad launch is (the prologue-fused forward variants keep their register budget).
+template <bool BNBOK, int NT, int MTS = 2, typename PixFn>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x4 (&acc)[MTS][NT], float* wlds, int n_base, PixFn pix,
                                               float (&s1)[8], float (&s2)[8]) {
     constexpr int LDW = EpiLds<NT>::LDW;
@@ -124,6 +96,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x4 (&a
     const int cc = lane % CPP;
     const int co0 = n_base + cc * 8;
     const bool ch_ok = co0 < a.Cout;
+    const bool bnb = BNBOK && a.bnb_scale != nullptr;
     float bv[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) bv[i] = (a.bias && ch_ok) ? a.bias[co0 + i] : 0.f;
@@ -138,7 +111,21 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x4 (&a
         const f32x4 hi = *(const f32x4*)(wlds + row * LDW + cc * 8 + 4);
         if (!ok) continue;
         float v[8] = {lo[0] + bv[0], lo[1] + bv[1], lo[2] + bv[2], lo[3] + bv[3], hi[0] + bv[4], hi[1] + bv[5], hi[2] + bv[6], hi[3] + bv[7]};
-        if (a.mask != nullptr) {        // fused ReLU backward of the main path (residual is added after it)
+        if (bnb) {                      // v = d(conv input); the conv input was relu(x*scale + shift): fold that apply's backward
+            const bf16x8 xv = *(const bf16x8*)((const bf16*)a.mask + m * a.Cout + co0);
+            const long so = (long)n * a.bnb_nstride + co0;
+            const f32x4 sc0 = *(const f32x4*)(a.bnb_scale + so), sc1 = *(const f32x4*)(a.bnb_scale + so + 4);
+            const f32x4 sh0 = *(const f32x4*)(a.bnb_shift + so), sh1 = *(const f32x4*)(a.bnb_shift + so + 4);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float xf = bf2f(xv[i]);
+                const float sc = i < 4 ? sc0[i & 3] : sc1[i & 3], sh = i < 4 ? sh0[i & 3] : sh1[i & 3];
+                const float d = (a.bnb_relu && !(xf * sc + sh > 0.f)) ? 0.f : v[i];
+                s1[i] += d;                 // -> d shift (statistics slot 0)
+                s2[i] += d * xf;            // -> d scale (statistics slot 1)
+                v[i] = d * sc;
+            }
+        } else if (a.mask != nullptr) {        // fused ReLU backward of the main path (residual is added after it)
             const bf16x8 mk = *(const bf16x8*)((const bf16*)a.mask + m * a.Cout + co0);
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = (bf2f(mk[i]) > 0.f) ? v[i] : 0.f;
@@ -173,58 +160,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x4 (&a
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             o[i] = f2bf(v[i]);
-            s1[i] += v[i];
-            s2[i] += v[i] * v[i];
+            if (!bnb) {
+                s1[i] += v[i];
+                s2[i] += v[i] * v[i];
+            }
         }
         *(bf16x8*)((bf16*)a.out + m * a.Cout + co0) = o;
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // the caller may overwrite the buffer (next half / next phase);
     __builtin_amdgcn_wave_barrier();                             // anything that touches ANOTHER wave's region needs a block barrier
-}
-
-// fold the per-lane statistics partials (lane owns channel chunk lane % (2*NT)) and add them to the
-// replicated statistics buffer: one atomic per channel per block.
-// The fold over the 64 / CPP lanes that share a chunk goes through a wave-private LDS matrix sx[16 values][64 lanes]
-// (XOR-swizzled columns): 16 stores + 64 / CPP loads per lane instead of a 16-value x log2(64 / CPP)-step shuffle
-// butterfly -- the flush was ~20 % of the instruction stream of the generator's 1x1 convolutions.
-#define STATS_SX_FLOATS (8 * 64)           // per wave (sums and sums of squares take turns)
-template <int NT>
-__device__ __forceinline__ void stats_flush(const ConvArgs& a, float (&s1)[8], float (&s2)[8], int n_base, float* red /*[4][NT*16][2]*/,
-                                            float* sx_all /* 4 * STATS_SX_FLOATS, free at this point */, int replica, int event) {
-    constexpr int CPP = NT * 2;
-    constexpr int SH = 64 / CPP;                      // lanes sharing a chunk
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float* sx = sx_all + wave * STATS_SX_FLOATS;
-    // wave-private matrix: LDS operations of one wave execute in order, no barrier needed between the phases
-#pragma unroll
-    for (int w = 0; w < 2; ++w) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) sx[i * 64 + (lane ^ i)] = w ? s2[i] : s1[i];
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // make the wave's stores visible to its other lanes
-        __builtin_amdgcn_wave_barrier();
-        if (lane < 8 * CPP) {                         // output (chunk cc, channel i of the chunk): 8 * CPP <= 64 per wave
-            const int cc = lane % CPP, i = lane / CPP;
-            float t = 0.f;
-#pragma unroll
-            for (int k = 0; k < SH; ++k) t += sx[i * 64 + ((cc + CPP * k) ^ i)];
-            red[(wave * NT * 16 + cc * 8 + i) * 2 + w] = t;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // phase 1 overwrites what other lanes of this wave just read
-        __builtin_amdgcn_wave_barrier();
-    }
-    __syncthreads();
-    const int t = threadIdx.x;
-    if (t < NT * 16 && n_base + t < a.Cout) {
-        float x1 = 0.f, x2 = 0.f;
-#pragma unroll
-        for (int wv = 0; wv < 4; ++wv) {
-            x1 += red[(wv * NT * 16 + t) * 2 + 0];
-            x2 += red[(wv * NT * 16 + t) * 2 + 1];
-        }
-        float* st = a.stats + ((long)event * STAT_REPL + replica % STAT_REPL) * 2 * a.Cout;
-        atomicAdd(st + n_base + t, x1);
-        atomicAdd(st + a.Cout + n_base + t, x2);
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -298,7 +242,7 @@ __global__ __launch_bounds__(256, 4) void conv_gather_kernel(ConvArgs a) {
     float s1[8], s2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
-    const bool need_hw = a.ra != nullptr && a.ra_rs != 0;
+    const bool need_hw = (a.ra != nullptr && a.ra_rs != 0) || a.bnb_scale != nullptr;
     auto pix = [&](int row, long& m, int& n, int& h, int& w) -> bool {
         m = m_base + row;
         n = h = w = 0;
@@ -316,10 +260,10 @@ __global__ __launch_bounds__(256, 4) void conv_gather_kernel(ConvArgs a) {
         for (int half = 0; half < 2; ++half) {
             auto pixh = [&](int row, long& m, int& n, int& h, int& w) -> bool { return pix(row + 16 * half, m, n, h, w); };
             const f32x4(&sub)[1][NT] = *reinterpret_cast<const f32x4(*)[1][NT]>(&acc[half]);
-            conv_epilogue<NT, 1>(a, sub, epi + wave * EROWS * EpiLds<NT>::LDW, n_base, pixh, s1, s2);
+            conv_epilogue<(!AFF && !RELU), NT, 1>(a, sub, epi + wave * EROWS * EpiLds<NT>::LDW, n_base, pixh, s1, s2);
         }
     } else {
-        conv_epilogue<NT>(a, acc, epi + wave * EROWS * EpiLds<NT>::LDW, n_base, pix, s1, s2);
+        conv_epilogue<(!AFF && !RELU), NT>(a, acc, epi + wave * EROWS * EpiLds<NT>::LDW, n_base, pix, s1, s2);
     }
     static_assert(4 * EROWS * EpiLds<NT>::LDW >= 4 * STATS_SX_FLOATS, "epilogue buffer doubles as the statistics scratch");
     if (a.stats != nullptr) {
@@ -376,7 +320,7 @@ static int launch_gather_pro(const ConvArgs& a, hipStream_t st) {
 #define HT_W 32
 
 template <bool AFF, bool RELU, int RS, int NT, int PF, int CIN>
-__global__ __launch_bounds__(256, ((CIN >= 64 && PF == 0) ? 2 : (CIN == 16 ? 4 : (CIN == 32 ? 3 : 1)))) void conv3x3_halo_kernel(ConvArgs a, int tiles_w, int tiles_h, int ntiles, int tpb, int nblk) {
+__global__ __launch_bounds__(256, ((CIN >= 64 && PF == 0) ? 2 : (CIN == 16 ? 4 : (CIN == 32 ? 3 : 1)))) void conv3x3_halo_kernel(ConvArgs a, int tiles_w, int tiles_h, int tpe, int tpb, int nblk, int bpe) {
     extern __shared__ __attribute__((aligned(16))) char smem_all[];
     __shared__ float red[4 * NT * 16 * 2];
     constexpr int AW = HT_W + 2, AH = HT_H + 2;
@@ -397,8 +341,11 @@ __global__ __launch_bounds__(256, ((CIN >= 64 && PF == 0) ? 2 : (CIN == 16 ? 4 :
         const int q = nblk / 8, r = nblk % 8, xcd = bid % 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
     }
-    const int t0 = bid * tpb;
-    const int t1 = min(t0 + tpb, ntiles);
+    // a block stays inside ONE event (tpe tiles, bpe blocks per event): its statistics go to that event's accumulators with a
+    // single flush at the end (a flush inside the tile loop costs the C = 16 / 32 variants 40-60 spilled VGPRs)
+    const int event = bid / bpe;
+    const int t0 = event * tpe + (bid - event * bpe) * tpb;
+    const int t1 = min(t0 + tpb, (event + 1) * tpe);
     const bool col_ok = (n_base + (NT - 1) * 16 + lr) < a.Cout;
 
     if (PF > 0) {   // weights -> LDS once per block
@@ -476,20 +423,9 @@ __global__ __launch_bounds__(256, ((CIN >= 64 && PF == 0) ? 2 : (CIN == 16 ? 4 :
     const bf16* wrow = (const bf16*)a.w + (long)(col_ok ? n_base + lr : 0) * KP + lg * 8;
 
     if (PF > 0 && t0 < t1) load_tile(t0);
-    int cur_event = -1;
     for (int t = t0; t < t1; ++t) {
         int n, h0, w0;
         tile_coords(t, n, h0, w0);
-        if (a.stats != nullptr) {       // per-event statistics: a persistent block that walks into the next event flushes first
-            const int ev = (a.n_per_event > 0) ? n / a.n_per_event : 0;
-            if (ev != cur_event && cur_event >= 0) {
-                stats_flush<NT>(a, s1, s2, n_base, red, (float*)smem, bid, cur_event);
-                __syncthreads();
-#pragma unroll
-                for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
-            }
-            cur_event = ev;
-        }
         if (AFF && n != aff_n) {        // block-uniform: (re)load this image's scale / shift rows
             __syncthreads();
             stage_aff(aff_s, a.src, n, Cin);
@@ -641,17 +577,21 @@ __global__ __launch_bounds__(256, ((CIN >= 64 && PF == 0) ? 2 : (CIN == 16 ? 4 :
                 return h < H && w < W;
             };
             const f32x4(&sub)[2][NT] = *reinterpret_cast<const f32x4(*)[2][NT]>(&acc[2 * half]);
-            conv_epilogue<NT>(a, sub, epi, n_base, pix, s1, s2);
+            conv_epilogue<(!AFF && !RELU), NT>(a, sub, epi, n_base, pix, s1, s2);
         }
         __syncthreads();      // every wave has left its epilogue buffer: the region is the next tile's halo / the fold scratch
     }
-    if (a.stats != nullptr && cur_event >= 0) stats_flush<NT>(a, s1, s2, n_base, red, (float*)smem, bid, cur_event);
+    if (a.stats != nullptr && t0 < t1) stats_flush<NT>(a, s1, s2, n_base, red, (float*)smem, bid, event);
 }
 
 template <bool AFF, bool RELU, int RS>
 static int launch_halo_nt(const ConvArgs& a, hipStream_t st) {
     const int tiles_w = (a.W + HT_W - 1) / HT_W, tiles_h = (a.H + HT_H - 1) / HT_H;
     const int ntiles = a.N * tiles_w * tiles_h;
+    // statistics groups: events of n_per_event images (forward: per-event BatchNorm statistics; BatchNorm-backward epilogue: every
+    // image its own group); without statistics the whole batch is one group
+    const int n_events = (a.stats != nullptr && a.n_per_event > 0) ? a.N / a.n_per_event : 1;
+    const int tpe = ntiles / n_events;
     const size_t halo = (size_t)(HT_H + 2) * (HT_W + 2) * (a.Cin * 2 + 16);
     int tpb = ntiles / 2048;
     if (tpb < 1) tpb = 1;
@@ -665,9 +605,10 @@ static int launch_halo_nt(const ConvArgs& a, hipStream_t st) {
         int tp = (PFV) > 0 ? tpb : 1;                                                                        \
         if ((PFV) > 0 && (CINV) >= 64) { tp = (ntiles + 255) / 256; if (tp > 8) tp = 8; }   /* one persistent block per CU */ \
         if ((PFV) > 0) lds += (size_t)NTV * 16 * (a.Kpad * 2 + 16);                                          \
-        const int nblk = (ntiles + tp - 1) / tp;                                                             \
+        const int bpe = (tpe + tp - 1) / tp;                                                                 \
+        const int nblk = bpe * n_events;                                                                     \
         hipLaunchKernelGGL((conv3x3_halo_kernel<AFF, RELU, RS, NTV, PFV, CINV>), dim3(nblk, (a.Cout + 16 * NTV - 1) / (16 * NTV)), \
-                           dim3(256), lds, st, a, tiles_w, tiles_h, ntiles, tp, nblk);                       \
+                           dim3(256), lds, st, a, tiles_w, tiles_h, tpe, tp, nblk, bpe);                     \
     }
     // prefetching variants: Cin = Cout = 16 / 32 (PF = ceil(340 * Cin/8 / 256) = 3 / 6)
     // small feature maps: fewer channels per block so that the grid still covers the 256 CUs
@@ -719,6 +660,9 @@ int conv_gather_launch(const ConvArgs& a, hipStream_t st) {
     if (a.ra && a.ra_rs == 1) CHECK_ARG(a.H % 2 == 0 && a.W % 2 == 0, "conv: upsampled residual needs even H, W");
     if (a.rb) CHECK_ARG(a.Crb % 8 == 0 && a.Crb >= a.Cout - a.Ca, "conv: bad residual-B channel count");
     CHECK_ARG(a.n_per_event >= 0 && (a.n_per_event == 0 || a.N % a.n_per_event == 0), "conv: N=%d is not a whole number of events of %d images", a.N, a.n_per_event);
+    if (a.bnb_scale != nullptr)
+        CHECK_ARG(a.src.scale == nullptr && a.src.relu == 0 && a.src.rs == 0 && a.bnb_shift != nullptr && a.mask != nullptr && a.stats != nullptr && a.n_per_event == 1 && a.bias == nullptr && a.Cout % 8 == 0 &&
+                  (a.bnb_nstride == 0 || a.bnb_nstride >= a.Cout), "conv: BatchNorm-backward epilogue needs a plain prologue, shift, x (mask), per-image accumulators (n_per_event = 1), no bias");
     if (a.stats != nullptr && a.n_per_event > 0 && a.n_per_event < a.N)
         CHECK_ARG(((long)a.n_per_event * a.H * a.W) % 128 == 0, "conv: per-event statistics need n_per_event*H*W %% 128 == 0 (%d*%d*%d)", a.n_per_event, a.H, a.W);
     const double flops = 2.0 * a.N * a.H * a.W * (double)a.Cout * a.taps * a.Cin;
@@ -743,7 +687,11 @@ int conv_gather_launch(const ConvArgs& a, hipStream_t st) {
         else if (a.src.rs == 1) rc = launch_gather_pro<9, 1>(a, st);
         else { ieagan_set_error("conv: 3x3 with pooled source is not instantiated"); return IEAGAN_EINVAL; }
     } else {
-        if (a.src.rs == 0) rc = launch_gather_pro<1, 0>(a, st);
+        if (a.src.rs == 0) {
+            // large maps: the streaming kernel (prefetched operands, weights in registers); otherwise one tile per block
+            if (!(a.flags & IEAGAN_CONV_FORCE_GATHER) && conv1x1_stream_launch(a, st)) rc = 0;
+            else rc = launch_gather_pro<1, 0>(a, st);
+        }
         else if (a.src.rs == 2) rc = launch_gather_pro<1, 2>(a, st);
         else { ieagan_set_error("conv: 1x1 with upsampled source is not instantiated"); return IEAGAN_EINVAL; }
     }

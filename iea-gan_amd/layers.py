@@ -205,8 +205,12 @@ class ccbn(nn.Module):
     def scale_shift(self, stats, bank, col_gain, col_bias, count, events=1):
         """Per-(n,c) scale / shift from the producer's per-event statistics and the generator-wide gain bank
         (``count``: elements per channel of one event)."""
-        return ops.BNFinalizeFn.apply(stats, bank.gb, bank, col_gain, col_bias, self.output_size, self.stored_mean,
-                                      self.stored_var, count, self.eps, 0.1, self.training, events)
+        link = ops.BNLink() if torch.is_grad_enabled() else None
+        s, t = ops.BNFinalizeFn.apply(stats, bank.gb, bank, col_gain, col_bias, self.output_size, self.stored_mean,
+                                      self.stored_var, count, self.eps, 0.1, self.training, events, link)
+        if link is not None:
+            s._bn_link = link          # read by the consuming conv's backward (ops.ConvFn): dgrad-fused BatchNorm backward
+        return s, t
 
     def forward(self, x, y):
         """Stand-alone ccbn (NCHW fp32 in/out): statistics + apply as two HIP passes."""

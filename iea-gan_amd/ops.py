@@ -382,8 +382,9 @@ class BNFinalizeFn(torch.autograd.Function):
     """ccbn: scale = rstd*(1+gain[n,c]), shift = bias[n,c] - mean*scale  (layers.py:656-689)."""
 
     @staticmethod
-    def forward(ctx, stats, gb, bank, col_gain, col_bias, C, run_mean, run_var, count, eps, momentum, training, events=1):
+    def forward(ctx, stats, gb, bank, col_gain, col_bias, C, run_mean, run_var, count, eps, momentum, training, events=1, link=None):
         """``count``: elements per channel of ONE event; ``stats`` [E, STAT_REPL, 2, C]."""
+        ctx.link = link
         N, ld = gb.shape
         dev = gb.device
         scale = torch.empty(N, C, dtype=torch.float32, device=dev)
@@ -406,15 +407,21 @@ class BNFinalizeFn(torch.autograd.Function):
         gbuf = bank.grad_buffer()
         E = ctx.events
         dstat = torch.empty(E, 2, C, dtype=torch.float32, device=gb.device)
-        dscale = dscale.contiguous() if dscale is not None else torch.zeros(N, C, device=gb.device)
-        dshift = dshift.contiguous() if dshift is not None else torch.zeros(N, C, device=gb.device)
+        acc = ctx.link.acc if ctx.link is not None else None
+        repl = 0
+        if acc is not None:        # the consumer conv's dgrad folded the apply backward in: replicated per-image accumulators
+            ctx.link.acc = None
+            dscale, dshift, repl = acc, acc, STAT_REPL
+        else:
+            dscale = dscale.contiguous() if dscale is not None else torch.zeros(N, C, device=gb.device)
+            dshift = dshift.contiguous() if dshift is not None else torch.zeros(N, C, device=gb.device)
         H.call("ieagan_bn_finalize_bwd", dscale.data_ptr(), dshift.data_ptr(), gb.data_ptr() + 4 * ctx.cols[0], ld, 1,
                mr.data_ptr(), float(ctx.count), int(ctx.training), gbuf.data_ptr() + 4 * ctx.cols[0],
-               gbuf.data_ptr() + 4 * ctx.cols[1], ld, dstat.data_ptr(), N, C, E, H.stream())
+               gbuf.data_ptr() + 4 * ctx.cols[1], ld, dstat.data_ptr(), N, C, E, repl, H.stream())
         bank.pending -= 1
         dgb = gbuf if bank.pending == 0 else None
         dstats = dstat.unsqueeze(1).expand(E, STAT_REPL, 2, C) if (ctx.has_stats and ctx.training) else None
-        return dstats, dgb, None, None, None, None, None, None, None, None, None, None, None
+        return dstats, dgb, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 class BNFinalizePlainFn(torch.autograd.Function):
@@ -450,7 +457,7 @@ class BNFinalizePlainFn(torch.autograd.Function):
         dscale = dscale.contiguous() if dscale is not None else torch.zeros(shape, device=dev)
         dshift = dshift.contiguous() if dshift is not None else torch.zeros(shape, device=dev)
         H.call("ieagan_bn_finalize_bwd", dscale.data_ptr(), dshift.data_ptr(), gain.data_ptr(), 0, 0, mr.data_ptr(),
-               float(ctx.count), int(ctx.training), dgain.data_ptr(), dbias.data_ptr(), 0, dstat.data_ptr(), rows, C, E,
+               float(ctx.count), int(ctx.training), dgain.data_ptr(), dbias.data_ptr(), 0, dstat.data_ptr(), rows, C, E, 0,
                H.stream())
         dstats = dstat.unsqueeze(1).expand(E, STAT_REPL, 2, C) if (ctx.has_stats and ctx.training) else None
         return dstats, dgain, dbias, None, None, None, None, None, None, None, None
@@ -460,14 +467,29 @@ class BNFinalizePlainFn(torch.autograd.Function):
 # Fused convolution
 # =====================================================================================================
 def _conv_launch(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu, N, Hc, Wc, Cin, Cout, taps, kpad, w, bias,
-                 ra, Cra, Ca, ra_rs, rb, Crb, mask, out, stats, ra_scale=1.0, npe=0, flags=0):
+                 ra, Cra, Ca, ra_rs, rb, Crb, mask, out, stats, ra_scale=1.0, npe=0, flags=0, bnb=None):
+    """``bnb`` = (scale, shift, nstride, relu): BatchNorm-apply backward fused into this (dgrad) launch -- ``mask`` is then the
+    BatchNorm input x and ``stats`` the per-image accumulators [N, STAT_REPL, 2, Cout] (``npe`` = 1), see include/ieagan_hip.h."""
+    bs, bt, bn, br = (H.ptr(bnb[0]), H.ptr(bnb[1]), int(bnb[2]), int(bool(bnb[3]))) if bnb is not None else (None, None, 0, 0)
     d = H.ConvDesc(N, Hc, Wc, Cin, Cout, taps, kpad, H.src_desc(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu),
                    H.ptr(w), H.ptr(bias), H.ptr(ra), Cra, Ca, ra_rs, float(ra_scale), H.ptr(rb), Crb, H.ptr(mask),
-                   H.ptr(out), H.ptr(stats), int(npe), int(flags))
+                   H.ptr(out), H.ptr(stats), int(npe), int(flags), bs, bt, bn, br)
     H.call("ieagan_conv_forward", d, H.stream())
 
 
 USE_TR_READ = True        # ds_read_b64_tr_b16 operand reads in conv_wgrad (False: scalar LDS reads)
+FUSE_BN_BACKWARD = True   # BatchNorm-apply backward inside the dgrad epilogue (False: the stand-alone prologue_bwd pass)
+
+
+class BNLink:
+    """Side channel between a conv's backward and the backward of the BatchNorm finalize that produced its prologue scale /
+    shift: when the dgrad kernel folds the BatchNorm-apply backward in, the per-image sums (d shift, d scale) arrive as replicated
+    accumulators [N, STAT_REPL, 2, C]; autograd is handed shape-correct placeholders and the finalize backward reads ``acc``."""
+    __slots__ = ("acc",)
+
+    def __init__(self):
+        self.acc = None
+
 FUSE_SHORTCUT_GRAD = True # add residual-shortcut gradients inside the dx-producing kernel (False: autograd adds)
 
 
@@ -492,6 +514,17 @@ class ResLink:
         out = (self.g, self.C, self.Ca, self.mode)
         self.g, self.ready = None, False
         return out
+
+
+_PLACEHOLDERS = {}
+
+
+def _placeholder(like):
+    """A zero tensor of ``like``'s shape that is never read (autograd insists on shape-correct gradients)."""
+    key = (tuple(like.shape), str(like.device))
+    if key not in _PLACEHOLDERS:
+        _PLACEHOLDERS[key] = torch.zeros(like.shape, dtype=torch.float32, device=like.device)
+    return _PLACEHOLDERS[key]
 
 
 class ConvFn(torch.autograd.Function):
@@ -585,7 +618,20 @@ class ConvFn(torch.autograd.Function):
                 res_in = None          # the shortcut operand needed no gradient (e.g. a detached block input)
             if res_in is not None:
                 lg, lC, lCa, lmode = res_in.take()
-            if res_in is not None and (fuse_mask or (plain and rs == 0)):
+            bn_link = getattr(scale, "_bn_link", None) if has_aff else None
+            if (FUSE_BN_BACKWARD and has_aff and rs == 0 and bn_link is not None and (Hs * Ws) % 128 == 0 and Cin % 8 == 0
+                    and (res_in is None or lmode in (0, 1))):
+                # BatchNorm apply + ReLU backward inside the dgrad epilogue: dx is written directly, the per-(n, c) sums go to
+                # replicated per-image accumulators that bn_finalize_bwd folds (no da tensor, no stand-alone pass over da / x)
+                dx = torch.empty(N, Hs, Ws, Cin, dtype=BF16, device=dev)
+                acc = zeros((N, STAT_REPL, 2, Cin), dev)
+                up = res_in is not None and lmode == 1          # shortcut gradient at double resolution: 2x2 SUM = 4 * average
+                _conv_launch(g, Cg, Hc, Wc, 0, None, None, 0, False, N, Hc, Wc, Cout, Cin, taps, rec.kpad2, rec.w_bwd, None,
+                             lg, lC or 0, lCa or 0, 2 if up else 0, None, 0, x, dx, acc, ra_scale=4.0 if up else 1.0, npe=1,
+                             bnb=(scale, shift, nstride, relu))
+                bn_link.acc = acc
+                dscale = dshift = _placeholder(scale)
+            elif res_in is not None and (fuse_mask or (plain and rs == 0)):
                 # bare-ReLU / no prologue (D blocks): the dgrad epilogue masks the main path and adds the
                 # shortcut gradient (0.25 * nearest-expand when the shortcut was average-pooled)
                 _conv_launch(g, Cg, Hc, Wc, 0, None, None, 0, False, N, Hc, Wc, Cout, Cin, taps, rec.kpad2, rec.w_bwd, None,

@@ -19,7 +19,7 @@ extern "C" {
 #endif
 
 const char* ieagan_last_error(void);
-#define IEAGAN_ABI_VERSION 3        /* bumped whenever a struct layout or a signature in this header changes */
+#define IEAGAN_ABI_VERSION 4        /* bumped whenever a struct layout or a signature in this header changes */
 int ieagan_abi_version(void);        /* == IEAGAN_ABI_VERSION of the header the library was built from */
 
 /* ---- profiling hooks (bench.py): per-kernel HIP-event timing on the launch stream ---- */
@@ -68,6 +68,17 @@ typedef struct {
     int n_per_event;      /* images per event: E = N / n_per_event statistics groups (BatchNorm statistics are
                            * intra-event); 0 or N = one event.  E > 1 needs n_per_event*H*W % 128 == 0 */
     int flags;            /* IEAGAN_CONV_FORCE_GATHER: route a 3x3 layer through the gather kernel (tests)    */
+    /* BatchNorm-apply backward fused into a dgrad launch (replaces the stand-alone pass over da / x that
+     * ieagan_prologue_bwd makes): with bnb_scale != NULL the accumulator tile da is NOT stored; per element
+     *   pre = x*scale[n,c] + shift[n,c];  d = (bnb_relu && pre <= 0) ? 0 : da;  out = d*scale[n,c] (+ residual A)
+     * where x is the tensor passed as `mask` (the BatchNorm input = the forward conv's source), and per image
+     *   stats[n][r][0][c] += sum d      (d shift)      stats[n][r][1][c] += sum d*x   (d scale)
+     * i.e. `stats` is fp32 [N][32][2][Cout] and n_per_event must be 1.  Reference: autograd of
+     * F.batch_norm(...)*(1+gain)+bias followed by ReLU (layers.py:656-689). */
+    const float* bnb_scale;
+    const float* bnb_shift;
+    int bnb_nstride;      /* image stride of bnb_scale / bnb_shift (0: per-channel rows shared by all images)  */
+    int bnb_relu;
 } ieagan_conv_desc;
 #define IEAGAN_CONV_FORCE_GATHER 1
 int ieagan_conv_forward(const ieagan_conv_desc* d, void* stream);
@@ -107,9 +118,11 @@ int ieagan_bn_finalize_fwd(const float* stats, float count, const float* gain, c
                            int plus_one, float eps, float momentum, int training, float* run_mean,
                            float* run_var, float* scale, float* shift, float* mean_rstd, int N, int C, int E,
                            void* stream);
+/* acc_repl > 0: dshift is ignored and dscale points at the replicated per-image accumulators [rows][acc_repl][2][C]
+ * ({sum d, sum d*x}) a BatchNorm-backward dgrad launch produced (ieagan_conv_desc.bnb_*); they are folded here. */
 int ieagan_bn_finalize_bwd(const float* dscale, const float* dshift, const float* gain, int ld, int plus_one,
                            const float* mean_rstd, float count, int training, float* dgain, float* dbias,
-                           int ldd, float* dstat, int N, int C, int E, void* stream);
+                           int ldd, float* dstat, int N, int C, int E, int acc_repl, void* stream);
 int ieagan_res_bwd(const void* g, int Cg, void* dr, int Cr, int Ca, int mode, int N, int Hr, int Wr, void* stream);
 /* stats (optional): fp32 [E][32][2][C] per-event replicated (sum, sumsq), E = N / n_per_event (0: one event) */
 int ieagan_nchw_to_nhwc(const float* in, void* out, float* stats, int N, int C, int HW, int n_per_event, void* stream);

@@ -180,6 +180,53 @@ def test_specialised_halo_variants_agree_with_gather(dev, N, Hh, Ww, C):
     close(outs[0][1], outs[1][1], 2e-3, "halo vs gather stats")
 
 
+@pytest.mark.parametrize("Cin,Cout,Hh,Ww,N,aff,relu,res,mask,events", [
+    (16, 32, 256, 768, 2, True, True, "up", False, 2),       # G b11 conv4: 4 m-tiles per wave, half-resolution shortcut, per-event statistics
+    (16, 64, 128, 384, 4, False, True, "same", True, 1),     # D s0.1 conv4 dgrad-like: mask + same-resolution residual
+    (32, 16, 256, 768, 2, False, False, None, True, 1),      # one n-tile (Cout = 16), mask
+    (64, 16, 128, 384, 4, True, True, None, False, 2),       # two k-steps, one n-tile, statistics of two events
+    (32, 64, 128, 384, 4, True, False, "cat", False, 1),     # residual A on channels [0, 32) + residual B on [32, 64)
+    (128, 32, 64, 192, 12, False, True, None, False, 1),     # four k-steps
+    (64, 128, 64, 192, 12, True, True, "pool", False, 1),    # grid.y = 2, double-resolution shortcut (2x2 average)
+])
+def test_streaming_1x1_agrees_with_gather(dev, Cin, Cout, Hh, Ww, N, aff, relu, res, mask, events):
+    """conv1x1_stream (prefetched operands, weights in registers, per-block statistics) against conv_gather (one tile per block) on
+    identical operands: same outputs bit for bit (same MFMA order per output) and the same per-event statistics."""
+    import _hip, ops
+    torch.manual_seed(21)
+    x = torch.randn(N, Hh, Ww, Cin, device=dev).to(BF)
+    kpad = ops._kpad(Cin)
+    w = torch.zeros(Cout, kpad, device=dev)
+    w[:, :Cin] = torch.randn(Cout, Cin, device=dev) / math.sqrt(Cin)
+    w = w.to(BF)
+    bias = 0.1 * torch.randn(Cout, device=dev)
+    sc = (1 + 0.3 * torch.randn(N, Cin, device=dev)) if aff else None
+    sh = (0.2 * torch.randn(N, Cin, device=dev)) if aff else None
+    mk = torch.randn(N, Hh, Ww, Cout, device=dev).to(BF) if mask else None
+    ra = rb = None
+    Cra = Ca = ra_rs = Crb = 0
+    if res == "same":
+        ra, Cra, Ca = torch.randn(N, Hh, Ww, Cout, device=dev).to(BF), Cout, Cout
+    elif res == "up":
+        ra, Cra, Ca, ra_rs = torch.randn(N, Hh // 2, Ww // 2, 2 * Cout, device=dev).to(BF), 2 * Cout, Cout, 1
+    elif res == "pool":
+        ra, Cra, Ca, ra_rs = torch.randn(N, 2 * Hh, 2 * Ww, Cout, device=dev).to(BF), Cout, Cout, 2
+    elif res == "cat":
+        ra, Cra, Ca = torch.randn(N, Hh, Ww, Cout // 2, device=dev).to(BF), Cout // 2, Cout // 2
+        rb, Crb = torch.randn(N, Hh, Ww, Cout // 2, device=dev).to(BF), Cout // 2
+    outs = []
+    for force in (0, _hip.CONV_FORCE_GATHER):
+        out = torch.empty(N, Hh, Ww, Cout, device=dev, dtype=BF)
+        st = ops.new_stats(Cout, dev, events)
+        ops._conv_launch(x, Cin, Hh, Ww, 0, sc, sh, Cin if aff else 0, relu, N, Hh, Ww, Cin, Cout, 1, kpad, w, bias, ra, Cra, Ca, ra_rs,
+                         rb, Crb, mk, out, st, npe=N // events, flags=force)
+        outs.append((out, st.sum(1)))
+    assert torch.equal(outs[0][0], outs[1][0]), float((outs[0][0].float() - outs[1][0].float()).abs().max())
+    close(outs[0][1], outs[1][1], 1e-4, "stream vs gather statistics")
+    if events > 1:
+        assert not torch.allclose(outs[0][1][0], outs[0][1][1])          # the events really are separate accumulators
+
+
 def conv_reference(x, W, u, bias, scale, shift, relu, rs, taps, ra, ra_mode, Ca, rb):
     """fp32 NCHW composite with the kernel's rounding points (A operand and weights in bf16)."""
     a = x
@@ -223,7 +270,7 @@ PROD_CASES = [
     (9, 64, 64, 32, 96, True, True, 0, None, True, 6),               # G b5/b6: C=64 pipelined K loop
     (9, 128, 128, 16, 48, True, True, 0, None, True, 8),             # G b3/b4, D s4.0: C=128
     (1, 16, 32, 256, 768, True, True, 0, ("up", 64, 32), True, 2),   # G b11 conv4 + upsampled, channel-dropped shortcut
-    (1, 64, 16, 128, 384, True, True, 0, None, True, 2),             # G b10/b11 conv1
+    (1, 64, 16, 128, 384, True, True, 0, None, True, 3),             # G b10/b11 conv1 (streaming 1x1 kernel from 1024 pixel groups)
     (1, 32, 16, 256, 768, False, False, 0, None, False, 2),          # D s0.0 conv1 (first block: no pre-activation)
     (1, 16, 64, 128, 384, False, True, 2, ("pool+sc", 32, 32), False, 2),   # D s0.0 conv4: pooled source + concat shortcut
     (1, 32, 32, 128, 384, False, False, 2, None, False, 2),          # D s0.0 conv_sc on the pooled block input
@@ -390,6 +437,69 @@ def test_bn_finalize_matches_batch_norm(dev):
     g = torch.autograd.grad((out.float() * nhwc(go).float()).sum(), [x2, gb2])
     close(g[0], gref[0], 3e-2, "bn dx")
     close(g[1], gref[1], 3e-2, "bn dgain/dbias")
+
+
+@pytest.mark.parametrize("taps,C,Cout,Hh,Ww,N,res", [(9, 16, 16, 64, 96, 3, None),        # halo dgrad kernel (C = 16 variant)
+                                                     (9, 64, 64, 16, 48, 3, None),        # halo dgrad kernel (C = 64)
+                                                     (1, 64, 16, 32, 64, 3, None),        # gather dgrad kernel
+                                                     (1, 32, 64, 128, 384, 3, "same"),    # streaming dgrad kernel + shortcut gradient
+                                                     (1, 64, 32, 128, 384, 3, "up")])     # ... with the shortcut at double resolution
+def test_bn_backward_fused_into_dgrad(dev, taps, C, Cout, Hh, Ww, N, res):
+    """ccbn -> ReLU -> conv: the BatchNorm-apply backward folded into the dgrad epilogue (per-image accumulators, no da tensor)
+    against (a) the stand-alone prologue_bwd pass and (b) fp32 PyTorch autograd of F.batch_norm * (1 + gain) + bias."""
+    import layers, ops
+    torch.manual_seed(23)
+    k = 3 if taps == 9 else 1
+    x = r16(torch.randn(N, C, Hh, Ww, device=dev) * 1.3 + 0.2)
+    gb = 0.3 * torch.randn(N, 2 * C, device=dev)
+    W = torch.randn(Cout, C, k, k, device=dev) / math.sqrt(C * taps)
+    u = torch.randn(1, Cout, device=dev)
+    go = r16(torch.randn(N, Cout, Hh, Ww, device=dev))
+    # shortcut that also reads x (GBlock: conv4's residual operand): its gradient is handed to this conv's backward through a ResLink
+    sg = None
+    if res == "same":
+        sg = r16(torch.randn(N, C, Hh, Ww, device=dev))
+    elif res == "up":
+        sg = r16(torch.randn(N, C, 2 * Hh, 2 * Ww, device=dev))
+
+    def hip(fused):
+        ops.FUSE_BN_BACKWARD = fused
+        try:
+            rec, Wv, _, _ = make_rec(W.clone(), u.clone(), torch.ones(1, device=dev))
+            x2, gb2 = x.clone().requires_grad_(True), gb.clone().requires_grad_(True)
+            xa, st = ops.ToNHWCFn.apply(x2, True)
+            bank = ops.GainBank(gb2, 1)
+            link = ops.BNLink()
+            s, t = ops.BNFinalizeFn.apply(st, gb2, bank, 0, C, C, torch.zeros(C, device=dev), torch.ones(C, device=dev), N * Hh * Ww, 1e-5,
+                                          0.1, True, 1, link)
+            s._bn_link = link
+            rl = None
+            if sg is not None:
+                rl = ops.ResLink()
+                rl.deposit(nhwc(sg), C, C, 1 if res == "up" else 0)
+            out, _ = ops.conv(xa, Wv.detach(), None, rec, taps, scale=s, shift=t, relu=True, res_in=rl)
+            gx, ggb = torch.autograd.grad((out.float() * nhwc(go).float()).sum(), [x2, gb2])
+            return nchw(out), gx, ggb
+        finally:
+            ops.FUSE_BN_BACKWARD = True
+
+    o1, gx1, gg1 = hip(True)
+    o0, gx0, gg0 = hip(False)
+    close(o1, o0, 8e-3, "forward")          # (the batch statistics are float-atomic sums: run-to-run differences of an ulp)
+    close(gx1, gx0, 8e-3, "dx fused vs separate")              # same arithmetic, one bf16 rounding fewer (da is never stored)
+    close(gg1, gg0, 8e-3, "d gain/bias fused vs separate")
+    xr, gbr = x.clone().requires_grad_(True), gb.clone().requires_grad_(True)
+    a = F.relu(F.batch_norm(xr, None, None, None, None, True, 0.1, 1e-5) * (1 + gbr[:, :C, None, None]) + gbr[:, C:, None, None])
+    a = a + (r16(a) - a).detach()
+    Wsn, _, _ = sn_ref(W, u)
+    ref = F.conv2d(a, r16(Wsn), None, 1, 1 if taps == 9 else 0)
+    loss = (ref * go).sum()
+    if sg is not None:
+        loss = loss + ((F.interpolate(xr, scale_factor=2) if res == "up" else xr) * sg).sum()
+    gxr, ggr = torch.autograd.grad(loss, [xr, gbr])
+    close(o1, ref, 1.5e-2, "out")
+    close(gx1, gxr, 3e-2, "dx vs fp32")
+    close(gg1, ggr, 3e-2, "d gain/bias vs fp32")
 
 
 def test_diffaug_and_cr(dev, golden_dir):
