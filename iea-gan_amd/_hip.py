@@ -13,7 +13,9 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libieagan_hip.so")
+CONV_NO_LDS_WEIGHTS = 2  # ieagan_conv_desc.flags bit: C = 64 / 128 3x3 layers through conv3x3_halo instead of conv3x3_lds
 CONV_FORCE_GATHER = 1   # ieagan_conv_desc.flags bit (tests): route a 3x3 layer through the gather kernel
+BNB_REPL = 8            # replicas of the per-image accumulators of a BatchNorm-backward dgrad launch (common.h)
 STAT_REPL = 32          # replicas of every (sum, sumsq) statistics buffer (common.h)
 SN_FIELDS = 16          # int64 fields per row of the spectral-norm layer table (sn.hip)
 

@@ -76,5 +76,6 @@ __device__ __forceinline__ float wave_sum(float v) {
 // than spread adds), so per-channel sums are spread over STAT_REPL replicas keyed by the block
 // index and folded by the consumer (bn_finalize / the python side).
 #define STAT_REPL 32
+#define BNB_REPL 8          // replicas of the per-image (d shift, d scale) accumulators of a BatchNorm-backward dgrad launch
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

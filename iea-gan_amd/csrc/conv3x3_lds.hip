@@ -1,0 +1,263 @@
+// conv3x3_lds: the 3x3 convolutions with Cin = Cout = 64 / 128 (SNConv2d 3x3 of the 16x48 ... 64x192 stages of G and D,
+// model.py:37-42, 515-520; forward and -- with the flipped / transposed pack -- dgrad).  These are the only layers of the
+// network at or above the bf16 ridge (288-576 FLOP/B), so the kernel is built around the MFMA pipe:
+//   * the whole weight slice of the block ([NT*16 couts][9*CIN] bf16, 73.7 KB) AND the input halo live in LDS, both UNPADDED
+//     with an XOR swizzle of their 16-byte chunks (a padded image does not fit 160 KB next to the weights); every MFMA operand
+//     is one conflict-free ds_read_b128.  (Measured on the previous design: the per-wave 16-byte weight fetches through L1 ran
+//     at ~16 B/clk/CU and left the MFMAs waiting -- K loop alone 60 of 106 us at 64x192.)
+//   * all global traffic of a tile is requested up front (weights + halo: ~20 independent 16-byte loads per thread), then the
+//     K loop runs from LDS only, software-pipelined one k-step ahead;
+//   * C = 64: 8 waves share one 16x32-pixel tile x 64 couts (two waves per SIMD: one wave's LDS reads overlap the other's
+//     MFMAs); C = 128: 4 waves, 8x16 pixels x 32 couts -- small tiles because these layers live on 8x24 / 16x48 maps and
+//     need >= 256 blocks to fill the chip.
+// Prologue (per-(n,c) affine + ReLU, nearest x2 upsample of the source) and epilogue (bias, ReLU mask, residual, statistics,
+// BatchNorm-backward mode) are those of conv3x3_halo (shared code in conv_common.h).
+#include "common.h"
+#include "conv_args.h"
+#include "conv_common.h"
+
+// 16-byte chunk swizzle of an LDS image with CPR chunks per row.  Rows are CPR*16 bytes apart, so the 16 lanes of a fragment
+// read (same chunk of 16 consecutive rows) would hit only one or two of the sixteen 16-byte bank slots.  The chunk index is
+// XOR-ed with a per-row key:  CPR % 16 == 8 -> the row parity already selects one half of the slots, permute the low 3 chunk
+// bits with key = (r >> 1) & 7;  CPR % 16 == 0 -> permute 4 bits with key = r & 15.  `r` only has to enumerate the 16 rows of
+// a fragment read bijectively: the weight image uses the row index, the halo image the COLUMN of the pixel inside its halo row
+// (16 consecutive pixels of a row), which keeps every read address = per-lane register + compile-time immediate.
+template <int CPR>
+__device__ __forceinline__ int swz_key(int r) {
+    static_assert(CPR % 16 == 8 || CPR % 16 == 0, "swizzle derived for rows of 8 or 16 (mod 16) chunks");
+    return (CPR % 16 == 8) ? ((r >> 1) & 7) : (r & 15);
+}
+template <int CPR>
+__device__ __forceinline__ int swz(int key, int chunk) {
+    constexpr int G = (CPR % 16 == 8) ? 8 : 16;
+    return (chunk & ~(G - 1)) | ((chunk ^ key) & (G - 1));
+}
+
+template <bool AFF, bool RELU, int RS, int CIN, int NT, int TH, int TW, int NW, bool BNB>
+__global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_lds_kernel(ConvArgs a, int tiles_w, int tiles_h, int tpe, int tpb, int nblk, int bpe) {
+    constexpr int AW = TW + 2, AH = TH + 2;
+    constexpr int K = 9 * CIN;
+    constexpr int KS = K / 32;
+    constexpr int CH = CIN / 8;                 // 16-byte chunks per halo pixel
+    constexpr int WCH = K / 8;                  // 16-byte chunks per weight row
+    constexpr int MTW = (TH * TW / 16) / NW;    // m-tiles (16 pixels of one tile row) per wave
+    constexpr int MPR = TW / 16;                // m-tiles per tile row
+    constexpr int NTHR = NW * 64;
+    static_assert(MTW >= 2 && MTW % 2 == 0 && (TH * TW / 16) % NW == 0, "each wave owns an even number of m-tiles");
+    constexpr int W_BYTES = NT * 16 * K * 2;
+    constexpr int HALO_BYTES = AH * AW * CIN * 2;
+    constexpr int EPI_BYTES = NW * EpiLds<NT>::FLOATS * 4;
+    static_assert(EPI_BYTES <= HALO_BYTES && NW * STATS_SX_FLOATS * 4 <= HALO_BYTES, "epilogue / fold scratch reuse the halo region");
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];
+    char* wsm = smem_all;                       // weights
+    char* hsm = smem_all + W_BYTES;             // halo, later the epilogue transpose buffers
+    __shared__ float red[NW * NT * 16 * 2];
+    __shared__ __attribute__((aligned(32))) float aff_s[AFF ? 2 * AFF_MAXC : 8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int H = a.H, W = a.W;
+    const int n_base = blockIdx.y * NT * 16;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk / 8, r = nblk % 8, xcd = bid % 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+    }
+    const int event = bid / bpe;
+    const int t0 = event * tpe + (bid - event * bpe) * tpb;
+    const int t1 = min(t0 + tpb, (event + 1) * tpe);
+    if (t0 >= t1) return;
+
+    // ---- weights -> LDS (swizzled), requested once per block
+    {
+        constexpr int TOT = NT * 16 * WCH;
+#pragma unroll
+        for (int idx = threadIdx.x; idx < TOT; idx += NTHR) {
+            const int row = idx / WCH, kc = idx - row * WCH;
+            bf16x8 v = zero8();
+            if (n_base + row < a.Cout) v = *(const bf16x8*)((const bf16*)a.w + (long)(n_base + row) * a.Kpad + kc * 8);
+            *(bf16x8*)(wsm + (row * WCH + swz<WCH>(swz_key<WCH>(row), kc)) * 16) = v;
+        }
+    }
+    float s1[8], s2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
+    int aff_n = -1;
+    for (int t = t0; t < t1; ++t) {
+        const int n = t / (tiles_w * tiles_h);
+        const int trem = t - n * tiles_w * tiles_h;
+        const int h0 = (trem / tiles_w) * TH, w0 = (trem % tiles_w) * TW;
+        if (AFF && n != aff_n) {
+            __syncthreads();
+            stage_aff(aff_s, a.src, n, CIN);
+            aff_n = n;
+        }
+        __syncthreads();              // previous tile's epilogue has left the halo region; the BatchNorm table is in place
+        // ---- halo -> LDS with the prologue applied: batches of SB independent loads per thread
+        {
+            constexpr int TOT = AH * AW * CH, ITERS = (TOT + NTHR - 1) / NTHR, SB = 10;
+#pragma unroll
+            for (int b0 = 0; b0 < ITERS; b0 += SB) {
+                bf16x8 rawb[SB];
+                unsigned okb = 0;
+#pragma unroll
+                for (int j = 0; j < SB; ++j) {
+                    const int idx = threadIdx.x + (b0 + j) * NTHR;
+                    if (b0 + j >= ITERS || idx >= TOT) continue;
+                    const int hp = idx / CH, cc = idx - hp * CH;
+                    const int hh = h0 - 1 + hp / AW, ww = w0 - 1 + hp % AW;
+                    if (hh >= 0 && hh < H && ww >= 0 && ww < W) {
+                        const int sh_ = (RS == 1) ? (hh >> 1) : hh, sw_ = (RS == 1) ? (ww >> 1) : ww;
+                        rawb[j] = *(const bf16x8*)((const bf16*)a.src.x + (((long)n * a.src.Hs + sh_) * a.src.Ws + sw_) * a.src.Cx + cc * 8);
+                        okb |= 1u << j;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < SB; ++j) {
+                    const int idx = threadIdx.x + (b0 + j) * NTHR;
+                    if (b0 + j >= ITERS || idx >= TOT) continue;
+                    const int hp = idx / CH, cc = idx - hp * CH;
+                    bf16x8 o = zero8();
+                    if (okb & (1u << j)) {
+                        if (!AFF && RELU) {
+                            o = relu8(rawb[j]);
+                        } else if (AFF || RELU) {
+                            float v[8];
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) v[i] = bf2f(rawb[j][i]);
+                            xform8<AFF, RELU>(v, a.src, n, cc * 8, aff_s);
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) o[i] = f2bf(v[i]);
+                        } else {
+                            o = rawb[j];
+                        }
+                    }
+                    *(bf16x8*)(hsm + (hp * CH + swz<CH>(swz_key<CH>(hp % AW), cc)) * 16) = o;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- K loop from LDS: wave owns m-tiles [wave*MTW, +MTW) (tile row mt / MPR, columns (mt % MPR)*16 ..)
+        f32x4 acc[MTW][NT];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // Fragment addresses = per-lane register (swizzled chunk offset) + immediate (tap / k-step / n-tile displacement):
+        //   A: pixel (row mt/MPR + dy, col (mt%MPR)*16 + lr + dx) of the halo, chunk cq*4 + lg of its CIN/8 chunks
+        //   B: weight row nt*16 + lr, chunk ks*4 + lg
+        constexpr int NV = CH / 4;          // swizzle variants of the chunk index (CIN / 32)
+        int offA[MTW][3][NV];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+            const int mt = wave * MTW + m;
+            const int col = (mt % MPR) * 16 + lr;
+            const int base = ((mt / MPR) * AW + col) * CH * 16;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                for (int v = 0; v < NV; ++v) offA[m][dx][v] = base + swz<CH>(swz_key<CH>(col + dx), v * 4 + lg) * 16;
+        }
+        int offB[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) offB[v] = lr * WCH * 16 + swz<WCH>(swz_key<WCH>(lr), v * 4 + lg) * 16;
+        auto lda = [&](int ks, bf16x8(&x)[MTW]) {
+            const int tap = (ks * 32) / CIN, cq = ((ks * 32) % CIN) / 32;
+            const int imm = ((tap / 3) * AW + (tap % 3)) * CH * 16;
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) x[m] = *(const bf16x8*)(hsm + offA[m][tap % 3][cq] + imm);
+        };
+        auto ldb = [&](int ks, bf16x8(&b)[NT]) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b[nt] = *(const bf16x8*)(wsm + offB[ks % NV] + nt * 16 * WCH * 16 + (ks / NV) * NV * 64);
+        };
+        bf16x8 aq[2][MTW], bq[2][NT];
+        lda(0, aq[0]);
+        ldb(0, bq[0]);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 1 < KS) {
+                lda(ks + 1, aq[(ks + 1) & 1]);
+                ldb(ks + 1, bq[(ks + 1) & 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[ks & 1][m], bq[ks & 1][nt], acc[m][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();              // halo consumed: its LDS becomes the per-wave epilogue transpose buffers
+        float* epi = (float*)hsm + wave * EpiLds<NT>::FLOATS;
+#pragma unroll
+        for (int half = 0; half < MTW / 2; ++half) {
+            const int mt = wave * MTW + 2 * half;          // two m-tiles: 32 consecutive pixels of one tile row when MPR == 2,
+            auto pix = [&](int row, long& m, int& nn, int& h, int& w) -> bool {     // one m-tile of each of two rows when MPR == 1
+                const int mtt = mt + (row >> 4);
+                nn = n;
+                h = h0 + mtt / MPR;
+                w = w0 + (mtt % MPR) * 16 + (row & 15);
+                m = ((long)n * H + h) * W + w;
+                return h < H && w < W;
+            };
+            const f32x4(&sub)[2][NT] = *reinterpret_cast<const f32x4(*)[2][NT]>(&acc[2 * half]);
+            conv_epilogue<BNB, NT>(a, sub, epi, n_base, pix, s1, s2);
+        }
+    }
+    if (a.stats != nullptr) {
+        __syncthreads();
+        stats_flush<NT, NW>(a, s1, s2, n_base, red, (float*)hsm, bid, event);
+    }
+}
+
+template <bool AFF, bool RELU, int RS, bool BNB>
+static int lds_launch(const ConvArgs& a, hipStream_t st) {
+    const int n_events = (a.stats != nullptr && a.n_per_event > 0) ? a.N / a.n_per_event : 1;
+#define LDS_LAUNCH(CINV, NTV, THV, TWV, NWV)                                                                                       \
+    {                                                                                                                              \
+        const int tiles_w = (a.W + TWV - 1) / TWV, tiles_h = (a.H + THV - 1) / THV;                                                \
+        const int ntiles = a.N * tiles_w * tiles_h;                                                                                \
+        const int tpe = ntiles / n_events;                                                                                         \
+        const int gy = (a.Cout + 16 * NTV - 1) / (16 * NTV);                                                                       \
+        /* one block per CU slot: a block reloads its weight slice only once, so let it walk several tiles on big maps */         \
+        int tpb = (ntiles * gy + 511) / 512;                                                                                       \
+        if (tpb < 1) tpb = 1;                                                                                                      \
+        if (tpb > tpe) tpb = tpe;                                                                                                  \
+        const int bpe = (tpe + tpb - 1) / tpb;                                                                                     \
+        const int nblk = bpe * n_events;                                                                                           \
+        const size_t lds = (size_t)NTV * 16 * 9 * CINV * 2 + (size_t)(THV + 2) * (TWV + 2) * CINV * 2;                             \
+        auto kern = conv3x3_lds_kernel<AFF, RELU, RS, CINV, NTV, THV, TWV, NWV, BNB>;                                              \
+        static bool attr_set = false;                                                                                              \
+        if (!attr_set) {                                                                                                           \
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {      \
+                ieagan_set_error("conv3x3_lds: cannot reserve %zu bytes of LDS", lds);                                             \
+                return IEAGAN_ELAUNCH;                                                                                             \
+            }                                                                                                                      \
+            attr_set = true;                                                                                                       \
+        }                                                                                                                          \
+        hipLaunchKernelGGL(kern, dim3(nblk, gy), dim3(NWV * 64), lds, st, a, tiles_w, tiles_h, tpe, tpb, nblk, bpe);               \
+        return 1;                                                                                                                  \
+    }
+    if (a.Cin == 64 && a.Cout % 64 == 0 && a.H >= 16 && a.W >= 32) LDS_LAUNCH(64, 4, 16, 32, 8)
+    if (a.Cin == 128 && a.Cout % 32 == 0 && a.H >= 8 && a.W >= 16) LDS_LAUNCH(128, 2, 8, 16, 4)
+#undef LDS_LAUNCH
+    return 0;
+}
+
+// 1 = launched, 0 = not applicable (caller falls back to conv3x3_halo), < 0 = error
+int conv3x3_lds_launch(const ConvArgs& a, hipStream_t st) {
+    if (a.taps != 9 || (a.src.rs != 0 && a.src.rs != 1) || a.Kpad != 9 * a.Cin || (a.Cin != 64 && a.Cin != 128)) return 0;
+    if (a.src.scale != nullptr && a.Cin > AFF_MAXC) return 0;
+    const bool aff = a.src.scale != nullptr, relu = a.src.relu != 0;
+    if (a.src.rs == 0) {
+        if (aff && relu) return lds_launch<true, true, 0, false>(a, st);
+        if (aff) return lds_launch<true, false, 0, false>(a, st);
+        if (relu) return lds_launch<false, true, 0, false>(a, st);
+        if (a.bnb_scale != nullptr) return lds_launch<false, false, 0, true>(a, st);
+        return lds_launch<false, false, 0, false>(a, st);
+    }
+    if (aff && relu) return lds_launch<true, true, 1, false>(a, st);
+    if (aff) return lds_launch<true, false, 1, false>(a, st);
+    if (relu) return lds_launch<false, true, 1, false>(a, st);
+    return lds_launch<false, false, 1, false>(a, st);
+}

@@ -41,9 +41,9 @@ __device__ __forceinline__ void xform8(float (&v)[8], const SrcDesc& s, int n, i
 // (XOR-swizzled columns): 16 stores + 64 / CPP loads per lane instead of a 16-value x log2(64 / CPP)-step shuffle
 // butterfly -- the flush was ~20 % of the instruction stream of the generator's 1x1 convolutions.
 #define STATS_SX_FLOATS (8 * 64)           // per wave (sums and sums of squares take turns)
-template <int NT>
-__device__ __forceinline__ void stats_flush(const ConvArgs& a, float (&s1)[8], float (&s2)[8], int n_base, float* red /*[4][NT*16][2]*/,
-                                            float* sx_all /* 4 * STATS_SX_FLOATS, free at this point */, int replica, int event) {
+template <int NT, int NW = 4>
+__device__ __forceinline__ void stats_flush(const ConvArgs& a, float (&s1)[8], float (&s2)[8], int n_base, float* red /*[NW][NT*16][2]*/,
+                                            float* sx_all /* NW * STATS_SX_FLOATS, free at this point */, int replica, int event) {
     constexpr int CPP = NT * 2;
     constexpr int SH = 64 / CPP;                      // lanes sharing a chunk
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -70,13 +70,127 @@ __device__ __forceinline__ void stats_flush(const ConvArgs& a, float (&s1)[8], f
     if (t < NT * 16 && n_base + t < a.Cout) {
         float x1 = 0.f, x2 = 0.f;
 #pragma unroll
-        for (int wv = 0; wv < 4; ++wv) {
+        for (int wv = 0; wv < NW; ++wv) {
             x1 += red[(wv * NT * 16 + t) * 2 + 0];
             x2 += red[(wv * NT * 16 + t) * 2 + 1];
         }
-        float* st = a.stats + ((long)event * STAT_REPL + replica % STAT_REPL) * 2 * a.Cout;
+        // (the per-image accumulators of the BatchNorm-backward epilogue see ~10x fewer adders per address: 8 replicas)
+        const int R = (a.bnb_scale != nullptr) ? BNB_REPL : STAT_REPL;
+        float* st = a.stats + ((long)event * R + replica % R) * 2 * a.Cout;
         atomicAdd(st + n_base + t, x1);
         atomicAdd(st + a.Cout + n_base + t, x2);
     }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Shared epilogue.  The MFMA accumulators of one wave (2 m-tiles x NT n-tiles = 32 pixels x 16*NT
+// channels) are transposed through a wave-private LDS buffer so that every lane then owns 8 consecutive
+// channels of one pixel: bias, ReLU-mask, residual and the output store are all 16-byte accesses, and
+// the per-channel (sum, sumsq) partials stay in registers of a fixed channel group per lane.
+//   pix(row, m, n, h, w) -> bool : pixel of wave-local row (0..31); m = linear NHW index
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+struct EpiLds {
+    static constexpr int LDW = NT * 16 + 4;             // padded row (floats): 4 rows apart -> 16 banks apart
+    static constexpr int FLOATS = 32 * LDW;
+};
+
+// BNBOK: the BatchNorm-backward epilogue mode (ieagan_conv_desc.bnb_*) is compiled in -- a separate instantiation of the
+// plain-prologue kernels (a dgrad launch has no prologue), so that every other variant keeps its register budget.
+template <bool BNBOK, int NT, int MTS = 2, typename PixFn>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x4 (&acc)[MTS][NT], float* wlds, int n_base, PixFn pix,
+                                              float (&s1)[8], float (&s2)[8]) {
+    constexpr int LDW = EpiLds<NT>::LDW;
+    constexpr int CPP = NT * 2;                         // 8-channel chunks per pixel
+    static_assert((16 * MTS * CPP) % 64 == 0, "epilogue rows x chunks must fill whole waves");
+    const int lane = threadIdx.x & 63;
+    const int lr = lane & 15, lg = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < MTS; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wlds[(mt * 16 + lg * 4 + r) * LDW + nt * 16 + lr] = acc[mt][nt][r];
+    // the transpose buffer is private to this wave: its LDS operations complete in order, the fence only pins the compiler
+    // (a block-wide barrier here made every wave wait for the slowest one four times per tile)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int cc = lane % CPP;
+    const int co0 = n_base + cc * 8;
+    const bool ch_ok = co0 < a.Cout;
+    const bool bnb = BNBOK && a.bnb_scale != nullptr;
+    float bv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bv[i] = (a.bias && ch_ok) ? a.bias[co0 + i] : 0.f;
+    const int H = a.H, W = a.W;
+#pragma unroll
+    for (int it = 0; it < (16 * MTS * CPP) / 64; ++it) {
+        const int row = (it * 64 + lane) / CPP;
+        long m;
+        int n, h, w;
+        const bool ok = pix(row, m, n, h, w) && ch_ok;
+        const f32x4 lo = *(const f32x4*)(wlds + row * LDW + cc * 8);
+        const f32x4 hi = *(const f32x4*)(wlds + row * LDW + cc * 8 + 4);
+        if (!ok) continue;
+        float v[8] = {lo[0] + bv[0], lo[1] + bv[1], lo[2] + bv[2], lo[3] + bv[3], hi[0] + bv[4], hi[1] + bv[5], hi[2] + bv[6], hi[3] + bv[7]};
+        if (bnb) {                      // v = d(conv input); the conv input was relu(x*scale + shift): fold that apply's backward
+            const bf16x8 xv = *(const bf16x8*)((const bf16*)a.mask + m * a.Cout + co0);
+            const long so = (long)n * a.bnb_nstride + co0;
+            const f32x4 sc0 = *(const f32x4*)(a.bnb_scale + so), sc1 = *(const f32x4*)(a.bnb_scale + so + 4);
+            const f32x4 sh0 = *(const f32x4*)(a.bnb_shift + so), sh1 = *(const f32x4*)(a.bnb_shift + so + 4);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float xf = bf2f(xv[i]);
+                const float sc = i < 4 ? sc0[i & 3] : sc1[i & 3], sh = i < 4 ? sh0[i & 3] : sh1[i & 3];
+                const float d = (a.bnb_relu && !(xf * sc + sh > 0.f)) ? 0.f : v[i];
+                s1[i] += d;                 // -> d shift (statistics slot 0)
+                s2[i] += d * xf;            // -> d scale (statistics slot 1)
+                v[i] = d * sc;
+            }
+        } else if (a.mask != nullptr) {        // fused ReLU backward of the main path (residual is added after it)
+            const bf16x8 mk = *(const bf16x8*)((const bf16*)a.mask + m * a.Cout + co0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (bf2f(mk[i]) > 0.f) ? v[i] : 0.f;
+        }
+        if (a.ra != nullptr && co0 < a.Ca) {
+            const bf16* ra = (const bf16*)a.ra;
+            float rv[8];
+            if (a.ra_rs == 0) {
+                const bf16x8 t = *(const bf16x8*)(ra + m * a.Cra + co0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) rv[i] = bf2f(t[i]);
+            } else if (a.ra_rs == 1) {      // operand lives at half resolution: nearest x2 upsample
+                const bf16x8 t = *(const bf16x8*)(ra + (((long)n * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1)) * a.Cra + co0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) rv[i] = bf2f(t[i]);
+            } else {                        // operand lives at double resolution: 2x2 average
+                const bf16* p = ra + (((long)n * (2 * H) + 2 * h) * (2 * W) + 2 * w) * a.Cra + co0;
+                const long rs_ = (long)2 * W * a.Cra;
+                const bf16x8 t0 = *(const bf16x8*)p, t1 = *(const bf16x8*)(p + a.Cra), t2 = *(const bf16x8*)(p + rs_),
+                             t3 = *(const bf16x8*)(p + rs_ + a.Cra);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) rv[i] = 0.25f * (bf2f(t0[i]) + bf2f(t1[i]) + bf2f(t2[i]) + bf2f(t3[i]));
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += a.ra_scale * rv[i];
+        } else if (a.rb != nullptr && co0 >= a.Ca) {
+            const bf16x8 t = *(const bf16x8*)((const bf16*)a.rb + m * a.Crb + (co0 - a.Ca));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += bf2f(t[i]);
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            o[i] = f2bf(v[i]);
+            if (!bnb) {
+                s1[i] += v[i];
+                s2[i] += v[i] * v[i];
+            }
+        }
+        *(bf16x8*)((bf16*)a.out + m * a.Cout + co0) = o;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // the caller may overwrite the buffer (next half / next phase);
+    __builtin_amdgcn_wave_barrier();                             // anything that touches ANOTHER wave's region needs a block barrier
 }
 

@@ -61,121 +61,10 @@ __device__ __forceinline__ bf16x8 gather8(const SrcDesc& s, int H, int W, int n,
 }
 
 // ------------------------------------------------------------------------------------------------
-// Shared epilogue.  The MFMA accumulators of one wave (2 m-tiles x NT n-tiles = 32 pixels x 16*NT
-// channels) are transposed through a wave-private LDS buffer so that every lane then owns 8 consecutive
-// channels of one pixel: bias, ReLU-mask, residual and the output store are all 16-byte accesses, and
-// the per-channel (sum, sumsq) partials stay in registers of a fixed channel group per lane.
-//   pix(row, m, n, h, w) -> bool : pixel of wave-local row (0..31); m = linear NHW index
-// ------------------------------------------------------------------------------------------------
-template <int NT>
-struct EpiLds {
-    static constexpr int LDW = NT * 16 + 4;             // padded row (floats): 4 rows apart -> 16 banks apart
-    static constexpr int FLOATS = 32 * LDW;
-};
-
-// BNBOK: the BatchNorm-backward epilogue mode (ieagan_conv_desc.bnb_*) is compiled in -- only for the plain-prologue variants,
-// which is what a dgrad launch is (the prologue-fused forward variants keep their register budget).
-template <bool BNBOK, int NT, int MTS = 2, typename PixFn>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x4 (&acc)[MTS][NT], float* wlds, int n_base, PixFn pix,
-                                              float (&s1)[8], float (&s2)[8]) {
-    constexpr int LDW = EpiLds<NT>::LDW;
-    constexpr int CPP = NT * 2;                         // 8-channel chunks per pixel
-    static_assert((16 * MTS * CPP) % 64 == 0, "epilogue rows x chunks must fill whole waves");
-    const int lane = threadIdx.x & 63;
-    const int lr = lane & 15, lg = lane >> 4;
-#pragma unroll
-    for (int mt = 0; mt < MTS; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) wlds[(mt * 16 + lg * 4 + r) * LDW + nt * 16 + lr] = acc[mt][nt][r];
-    // the transpose buffer is private to this wave: its LDS operations complete in order, the fence only pins the compiler
-    // (a block-wide barrier here made every wave wait for the slowest one four times per tile)
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const int cc = lane % CPP;
-    const int co0 = n_base + cc * 8;
-    const bool ch_ok = co0 < a.Cout;
-    const bool bnb = BNBOK && a.bnb_scale != nullptr;
-    float bv[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) bv[i] = (a.bias && ch_ok) ? a.bias[co0 + i] : 0.f;
-    const int H = a.H, W = a.W;
-#pragma unroll
-    for (int it = 0; it < (16 * MTS * CPP) / 64; ++it) {
-        const int row = (it * 64 + lane) / CPP;
-        long m;
-        int n, h, w;
-        const bool ok = pix(row, m, n, h, w) && ch_ok;
-        const f32x4 lo = *(const f32x4*)(wlds + row * LDW + cc * 8);
-        const f32x4 hi = *(const f32x4*)(wlds + row * LDW + cc * 8 + 4);
-        if (!ok) continue;
-        float v[8] = {lo[0] + bv[0], lo[1] + bv[1], lo[2] + bv[2], lo[3] + bv[3], hi[0] + bv[4], hi[1] + bv[5], hi[2] + bv[6], hi[3] + bv[7]};
-        if (bnb) {                      // v = d(conv input); the conv input was relu(x*scale + shift): fold that apply's backward
-            const bf16x8 xv = *(const bf16x8*)((const bf16*)a.mask + m * a.Cout + co0);
-            const long so = (long)n * a.bnb_nstride + co0;
-            const f32x4 sc0 = *(const f32x4*)(a.bnb_scale + so), sc1 = *(const f32x4*)(a.bnb_scale + so + 4);
-            const f32x4 sh0 = *(const f32x4*)(a.bnb_shift + so), sh1 = *(const f32x4*)(a.bnb_shift + so + 4);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float xf = bf2f(xv[i]);
-                const float sc = i < 4 ? sc0[i & 3] : sc1[i & 3], sh = i < 4 ? sh0[i & 3] : sh1[i & 3];
-                const float d = (a.bnb_relu && !(xf * sc + sh > 0.f)) ? 0.f : v[i];
-                s1[i] += d;                 // -> d shift (statistics slot 0)
-                s2[i] += d * xf;            // -> d scale (statistics slot 1)
-                v[i] = d * sc;
-            }
-        } else if (a.mask != nullptr) {        // fused ReLU backward of the main path (residual is added after it)
-            const bf16x8 mk = *(const bf16x8*)((const bf16*)a.mask + m * a.Cout + co0);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = (bf2f(mk[i]) > 0.f) ? v[i] : 0.f;
-        }
-        if (a.ra != nullptr && co0 < a.Ca) {
-            const bf16* ra = (const bf16*)a.ra;
-            float rv[8];
-            if (a.ra_rs == 0) {
-                const bf16x8 t = *(const bf16x8*)(ra + m * a.Cra + co0);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) rv[i] = bf2f(t[i]);
-            } else if (a.ra_rs == 1) {      // operand lives at half resolution: nearest x2 upsample
-                const bf16x8 t = *(const bf16x8*)(ra + (((long)n * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1)) * a.Cra + co0);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) rv[i] = bf2f(t[i]);
-            } else {                        // operand lives at double resolution: 2x2 average
-                const bf16* p = ra + (((long)n * (2 * H) + 2 * h) * (2 * W) + 2 * w) * a.Cra + co0;
-                const long rs_ = (long)2 * W * a.Cra;
-                const bf16x8 t0 = *(const bf16x8*)p, t1 = *(const bf16x8*)(p + a.Cra), t2 = *(const bf16x8*)(p + rs_),
-                             t3 = *(const bf16x8*)(p + rs_ + a.Cra);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) rv[i] = 0.25f * (bf2f(t0[i]) + bf2f(t1[i]) + bf2f(t2[i]) + bf2f(t3[i]));
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] += a.ra_scale * rv[i];
-        } else if (a.rb != nullptr && co0 >= a.Ca) {
-            const bf16x8 t = *(const bf16x8*)((const bf16*)a.rb + m * a.Crb + (co0 - a.Ca));
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] += bf2f(t[i]);
-        }
-        bf16x8 o;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            o[i] = f2bf(v[i]);
-            if (!bnb) {
-                s1[i] += v[i];
-                s2[i] += v[i] * v[i];
-            }
-        }
-        *(bf16x8*)((bf16*)a.out + m * a.Cout + co0) = o;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // the caller may overwrite the buffer (next half / next phase);
-    __builtin_amdgcn_wave_barrier();                             // anything that touches ANOTHER wave's region needs a block barrier
-}
-
-// ------------------------------------------------------------------------------------------------
 // conv_gather: block = 4 waves, each wave 2 m-tiles (32 pixels) x NT n-tiles (16*NT channels);
 // A fragments gathered straight from global memory (any H, W; 1x1 and small 3x3 layers).
 // ------------------------------------------------------------------------------------------------
-template <int TAPS, bool AFF, bool RELU, int RS, int NT, bool LAFF>
+template <int TAPS, bool AFF, bool RELU, int RS, int NT, bool LAFF, bool BNB = false>
 __global__ __launch_bounds__(256, 4) void conv_gather_kernel(ConvArgs a) {
     // NT >= 2: the epilogue transposes 16 pixel rows at a time (half the LDS -> more resident blocks for this latency-bound kernel)
     constexpr int EROWS = (NT >= 2) ? 16 : 32;
@@ -242,7 +131,7 @@ __global__ __launch_bounds__(256, 4) void conv_gather_kernel(ConvArgs a) {
     float s1[8], s2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
-    const bool need_hw = (a.ra != nullptr && a.ra_rs != 0) || a.bnb_scale != nullptr;
+    const bool need_hw = (a.ra != nullptr && a.ra_rs != 0) || (BNB && a.bnb_scale != nullptr);
     auto pix = [&](int row, long& m, int& n, int& h, int& w) -> bool {
         m = m_base + row;
         n = h = w = 0;
@@ -260,10 +149,10 @@ __global__ __launch_bounds__(256, 4) void conv_gather_kernel(ConvArgs a) {
         for (int half = 0; half < 2; ++half) {
             auto pixh = [&](int row, long& m, int& n, int& h, int& w) -> bool { return pix(row + 16 * half, m, n, h, w); };
             const f32x4(&sub)[1][NT] = *reinterpret_cast<const f32x4(*)[1][NT]>(&acc[half]);
-            conv_epilogue<(!AFF && !RELU), NT, 1>(a, sub, epi + wave * EROWS * EpiLds<NT>::LDW, n_base, pixh, s1, s2);
+            conv_epilogue<BNB, NT, 1>(a, sub, epi + wave * EROWS * EpiLds<NT>::LDW, n_base, pixh, s1, s2);
         }
     } else {
-        conv_epilogue<(!AFF && !RELU), NT>(a, acc, epi + wave * EROWS * EpiLds<NT>::LDW, n_base, pix, s1, s2);
+        conv_epilogue<BNB, NT>(a, acc, epi + wave * EROWS * EpiLds<NT>::LDW, n_base, pix, s1, s2);
     }
     static_assert(4 * EROWS * EpiLds<NT>::LDW >= 4 * STATS_SX_FLOATS, "epilogue buffer doubles as the statistics scratch");
     if (a.stats != nullptr) {
@@ -274,7 +163,7 @@ __global__ __launch_bounds__(256, 4) void conv_gather_kernel(ConvArgs a) {
     }
 }
 
-template <int TAPS, bool AFF, bool RELU, int RS>
+template <int TAPS, bool AFF, bool RELU, int RS, bool BNB = false>
 static int launch_gather_nt(const ConvArgs& a, hipStream_t st) {
     const long M = (long)a.N * a.H * a.W;
     const unsigned gx = (unsigned)((M + 127) / 128);
@@ -284,8 +173,8 @@ static int launch_gather_nt(const ConvArgs& a, hipStream_t st) {
     const bool laff = AFF && ((long)a.H * a.W) % 128 == 0 && a.Cin <= AFF_MAXC;
 #define GATHER_LAUNCH(NTV, GY)                                                                                                  \
     {                                                                                                                           \
-        if (AFF && laff) hipLaunchKernelGGL((conv_gather_kernel<TAPS, AFF, RELU, RS, NTV, AFF>), dim3(gx, GY), dim3(256), 0, st, a); \
-        else hipLaunchKernelGGL((conv_gather_kernel<TAPS, AFF, RELU, RS, NTV, false>), dim3(gx, GY), dim3(256), 0, st, a);      \
+        if (AFF && laff) hipLaunchKernelGGL((conv_gather_kernel<TAPS, AFF, RELU, RS, NTV, AFF, BNB>), dim3(gx, GY), dim3(256), 0, st, a); \
+        else hipLaunchKernelGGL((conv_gather_kernel<TAPS, AFF, RELU, RS, NTV, false, BNB>), dim3(gx, GY), dim3(256), 0, st, a);      \
     }
     if (a.Cout % 64 == 0 && !small4) GATHER_LAUNCH(4, a.Cout / 64)
     else if (a.Cout % 32 == 0 && !(small4 && small2 && a.Cout % 64 == 0)) GATHER_LAUNCH(2, a.Cout / 32)
@@ -300,6 +189,7 @@ static int launch_gather_pro(const ConvArgs& a, hipStream_t st) {
     if (aff && relu) return launch_gather_nt<TAPS, true, true, RS>(a, st);
     if (aff) return launch_gather_nt<TAPS, true, false, RS>(a, st);
     if (relu) return launch_gather_nt<TAPS, false, true, RS>(a, st);
+    if (RS == 0 && a.bnb_scale != nullptr) return launch_gather_nt<TAPS, false, false, (RS == 0 ? 0 : RS), (RS == 0)>(a, st);   // BatchNorm-backward epilogue
     return launch_gather_nt<TAPS, false, false, RS>(a, st);
 }
 
@@ -319,7 +209,7 @@ static int launch_gather_pro(const ConvArgs& a, hipStream_t st) {
 #define HT_H 8
 #define HT_W 32
 
-template <bool AFF, bool RELU, int RS, int NT, int PF, int CIN>
+template <bool AFF, bool RELU, int RS, int NT, int PF, int CIN, bool BNB = false>
 __global__ __launch_bounds__(256, ((CIN >= 64 && PF == 0) ? 2 : (CIN == 16 ? 4 : (CIN == 32 ? 3 : 1)))) void conv3x3_halo_kernel(ConvArgs a, int tiles_w, int tiles_h, int tpe, int tpb, int nblk, int bpe) {
     extern __shared__ __attribute__((aligned(16))) char smem_all[];
     __shared__ float red[4 * NT * 16 * 2];
@@ -577,14 +467,14 @@ __global__ __launch_bounds__(256, ((CIN >= 64 && PF == 0) ? 2 : (CIN == 16 ? 4 :
                 return h < H && w < W;
             };
             const f32x4(&sub)[2][NT] = *reinterpret_cast<const f32x4(*)[2][NT]>(&acc[2 * half]);
-            conv_epilogue<(!AFF && !RELU), NT>(a, sub, epi, n_base, pix, s1, s2);
+            conv_epilogue<BNB, NT>(a, sub, epi, n_base, pix, s1, s2);
         }
         __syncthreads();      // every wave has left its epilogue buffer: the region is the next tile's halo / the fold scratch
     }
     if (a.stats != nullptr && t0 < t1) stats_flush<NT>(a, s1, s2, n_base, red, (float*)smem, bid, event);
 }
 
-template <bool AFF, bool RELU, int RS>
+template <bool AFF, bool RELU, int RS, bool BNB = false>
 static int launch_halo_nt(const ConvArgs& a, hipStream_t st) {
     const int tiles_w = (a.W + HT_W - 1) / HT_W, tiles_h = (a.H + HT_H - 1) / HT_H;
     const int ntiles = a.N * tiles_w * tiles_h;
@@ -607,7 +497,7 @@ static int launch_halo_nt(const ConvArgs& a, hipStream_t st) {
         if ((PFV) > 0) lds += (size_t)NTV * 16 * (a.Kpad * 2 + 16);                                          \
         const int bpe = (tpe + tp - 1) / tp;                                                                 \
         const int nblk = bpe * n_events;                                                                     \
-        hipLaunchKernelGGL((conv3x3_halo_kernel<AFF, RELU, RS, NTV, PFV, CINV>), dim3(nblk, (a.Cout + 16 * NTV - 1) / (16 * NTV)), \
+        hipLaunchKernelGGL((conv3x3_halo_kernel<AFF, RELU, RS, NTV, PFV, CINV, BNB>), dim3(nblk, (a.Cout + 16 * NTV - 1) / (16 * NTV)), \
                            dim3(256), lds, st, a, tiles_w, tiles_h, tpe, tp, nblk, bpe);                     \
     }
     // prefetching variants: Cin = Cout = 16 / 32 (PF = ceil(340 * Cin/8 / 256) = 3 / 6)
@@ -643,6 +533,7 @@ static int launch_halo_pro(const ConvArgs& a, hipStream_t st) {
     if (aff && relu) return launch_halo_nt<true, true, RS>(a, st);
     if (aff) return launch_halo_nt<true, false, RS>(a, st);
     if (relu) return launch_halo_nt<false, true, RS>(a, st);
+    if (RS == 0 && a.bnb_scale != nullptr) return launch_halo_nt<false, false, (RS == 0 ? 0 : RS), (RS == 0)>(a, st);             // BatchNorm-backward epilogue
     return launch_halo_nt<false, false, RS>(a, st);
 }
 
@@ -681,7 +572,11 @@ int conv_gather_launch(const ConvArgs& a, hipStream_t st) {
     ProfScope prof(a.taps == 9 ? (halo ? "conv3x3_halo" : "conv3x3_gather") : "conv1x1_gather", flops, bytes, st, tag, bytes_min);
     int rc;
     if (halo) {
-        rc = (a.src.rs == 0) ? launch_halo_pro<0>(a, st) : launch_halo_pro<1>(a, st);
+        // C = 64 / 128: weights + halo resident in LDS (conv3x3_lds.hip); everything else: conv3x3_halo
+        rc = (a.flags & IEAGAN_CONV_NO_LDS_WEIGHTS) ? 0 : conv3x3_lds_launch(a, st);
+        if (rc < 0) return rc;
+        if (rc == 0) rc = (a.src.rs == 0) ? launch_halo_pro<0>(a, st) : launch_halo_pro<1>(a, st);
+        else rc = 0;
     } else if (a.taps == 9) {
         if (a.src.rs == 0) rc = launch_gather_pro<9, 0>(a, st);
         else if (a.src.rs == 1) rc = launch_gather_pro<9, 1>(a, st);

@@ -411,7 +411,7 @@ class BNFinalizeFn(torch.autograd.Function):
         repl = 0
         if acc is not None:        # the consumer conv's dgrad folded the apply backward in: replicated per-image accumulators
             ctx.link.acc = None
-            dscale, dshift, repl = acc, acc, STAT_REPL
+            dscale, dshift, repl = acc, acc, H.BNB_REPL
         else:
             dscale = dscale.contiguous() if dscale is not None else torch.zeros(N, C, device=gb.device)
             dshift = dshift.contiguous() if dshift is not None else torch.zeros(N, C, device=gb.device)
@@ -469,7 +469,7 @@ class BNFinalizePlainFn(torch.autograd.Function):
 def _conv_launch(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu, N, Hc, Wc, Cin, Cout, taps, kpad, w, bias,
                  ra, Cra, Ca, ra_rs, rb, Crb, mask, out, stats, ra_scale=1.0, npe=0, flags=0, bnb=None):
     """``bnb`` = (scale, shift, nstride, relu): BatchNorm-apply backward fused into this (dgrad) launch -- ``mask`` is then the
-    BatchNorm input x and ``stats`` the per-image accumulators [N, STAT_REPL, 2, Cout] (``npe`` = 1), see include/ieagan_hip.h."""
+    BatchNorm input x and ``stats`` the per-image accumulators [N, BNB_REPL, 2, Cout] (``npe`` = 1), see include/ieagan_hip.h."""
     bs, bt, bn, br = (H.ptr(bnb[0]), H.ptr(bnb[1]), int(bnb[2]), int(bool(bnb[3]))) if bnb is not None else (None, None, 0, 0)
     d = H.ConvDesc(N, Hc, Wc, Cin, Cout, taps, kpad, H.src_desc(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu),
                    H.ptr(w), H.ptr(bias), H.ptr(ra), Cra, Ca, ra_rs, float(ra_scale), H.ptr(rb), Crb, H.ptr(mask),
@@ -484,7 +484,7 @@ FUSE_BN_BACKWARD = True   # BatchNorm-apply backward inside the dgrad epilogue (
 class BNLink:
     """Side channel between a conv's backward and the backward of the BatchNorm finalize that produced its prologue scale /
     shift: when the dgrad kernel folds the BatchNorm-apply backward in, the per-image sums (d shift, d scale) arrive as replicated
-    accumulators [N, STAT_REPL, 2, C]; autograd is handed shape-correct placeholders and the finalize backward reads ``acc``."""
+    accumulators [N, BNB_REPL, 2, C]; autograd is handed shape-correct placeholders and the finalize backward reads ``acc``."""
     __slots__ = ("acc",)
 
     def __init__(self):
@@ -624,7 +624,7 @@ class ConvFn(torch.autograd.Function):
                 # BatchNorm apply + ReLU backward inside the dgrad epilogue: dx is written directly, the per-(n, c) sums go to
                 # replicated per-image accumulators that bn_finalize_bwd folds (no da tensor, no stand-alone pass over da / x)
                 dx = torch.empty(N, Hs, Ws, Cin, dtype=BF16, device=dev)
-                acc = zeros((N, STAT_REPL, 2, Cin), dev)
+                acc = zeros((N, H.BNB_REPL, 2, Cin), dev)
                 up = res_in is not None and lmode == 1          # shortcut gradient at double resolution: 2x2 SUM = 4 * average
                 _conv_launch(g, Cg, Hc, Wc, 0, None, None, 0, False, N, Hc, Wc, Cout, Cin, taps, rec.kpad2, rec.w_bwd, None,
                              lg, lC or 0, lCa or 0, 2 if up else 0, None, 0, x, dx, acc, ra_scale=4.0 if up else 1.0, npe=1,

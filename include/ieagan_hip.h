@@ -67,13 +67,13 @@ typedef struct {
     float* stats;         /* fp32 [E][32][2][Cout] replicated (sum, sumsq) per event, accumulated; or NULL */
     int n_per_event;      /* images per event: E = N / n_per_event statistics groups (BatchNorm statistics are
                            * intra-event); 0 or N = one event.  E > 1 needs n_per_event*H*W % 128 == 0 */
-    int flags;            /* IEAGAN_CONV_FORCE_GATHER: route a 3x3 layer through the gather kernel (tests)    */
+    int flags;            /* IEAGAN_CONV_* bits below (kernel selection overrides for tests / benchmarks)        */
     /* BatchNorm-apply backward fused into a dgrad launch (replaces the stand-alone pass over da / x that
      * ieagan_prologue_bwd makes): with bnb_scale != NULL the accumulator tile da is NOT stored; per element
      *   pre = x*scale[n,c] + shift[n,c];  d = (bnb_relu && pre <= 0) ? 0 : da;  out = d*scale[n,c] (+ residual A)
      * where x is the tensor passed as `mask` (the BatchNorm input = the forward conv's source), and per image
      *   stats[n][r][0][c] += sum d      (d shift)      stats[n][r][1][c] += sum d*x   (d scale)
-     * i.e. `stats` is fp32 [N][32][2][Cout] and n_per_event must be 1.  Reference: autograd of
+     * i.e. `stats` is fp32 [N][8][2][Cout] (8 replicas) and n_per_event must be 1.  Reference: autograd of
      * F.batch_norm(...)*(1+gain)+bias followed by ReLU (layers.py:656-689). */
     const float* bnb_scale;
     const float* bnb_shift;
@@ -81,6 +81,7 @@ typedef struct {
     int bnb_relu;
 } ieagan_conv_desc;
 #define IEAGAN_CONV_FORCE_GATHER 1
+#define IEAGAN_CONV_NO_LDS_WEIGHTS 2   /* tests / benchmarks: C = 64 / 128 3x3 layers through conv3x3_halo instead of conv3x3_lds */
 int ieagan_conv_forward(const ieagan_conv_desc* d, void* stream);
 
 /* ---- weight gradient: dWp[Cout][Kpad] += G^T A   (autograd of F.conv2d w.r.t. weight) -------- */

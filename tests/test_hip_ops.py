@@ -152,9 +152,11 @@ def test_halo_and_gather_kernels_agree(dev):
     close(outs[0][1], outs[1][1], 1e-3, "halo vs gather stats")
 
 
-@pytest.mark.parametrize("N,Hh,Ww,C", [(40, 64, 192, 64),      # LDS-resident weights, persistent blocks (>= 1024 tiles)
-                                       (6, 32, 96, 64),        # C = 64 with weights through L1, pipelined K loop
-                                       (4, 16, 48, 128),       # C = 128
+@pytest.mark.parametrize("N,Hh,Ww,C", [(40, 64, 192, 64),      # C = 64: conv3x3_lds (8 waves, 16x32 tiles) / halo kernel with LDS weights
+                                       (6, 32, 96, 64),        # C = 64 on a small map
+                                       (5, 20, 40, 64),        # C = 64, ragged tiles (20 % 16, 40 % 32)
+                                       (4, 16, 48, 128),       # C = 128: conv3x3_lds (4 waves, 8x16 tiles)
+                                       (3, 8, 24, 128),        # C = 128 on the 8x24 map (ragged columns)
                                        (8, 128, 96, 32),       # C = 32: prefetching variant, unrolled K loop
                                        (4, 100, 70, 16)])      # C = 16: prefetching variant, ragged tiles
 def test_specialised_halo_variants_agree_with_gather(dev, N, Hh, Ww, C):
@@ -170,14 +172,16 @@ def test_specialised_halo_variants_agree_with_gather(dev, N, Hh, Ww, C):
     bias = 0.1 * torch.randn(C, device=dev)
     mask = torch.randn(N, Hh, Ww, C, device=dev).to(BF)
     outs = []
-    for force in (0, _hip.CONV_FORCE_GATHER):
+    for force in (0, _hip.CONV_FORCE_GATHER, _hip.CONV_NO_LDS_WEIGHTS):      # conv3x3_lds (C = 64 / 128) | conv_gather | conv3x3_halo
         out = torch.empty(N, Hh, Ww, C, device=dev, dtype=BF)
         st = ops.new_stats(C, dev)
         ops._conv_launch(x, C, Hh, Ww, 0, None, None, 0, True, N, Hh, Ww, C, C, 9, kpad, w, bias, None, 0, 0, 0, None, 0, mask, out, st,
                          flags=force)
         outs.append((out, st.sum((0, 1))))
-    close(outs[0][0], outs[1][0], 4e-3, "halo vs gather out")
-    close(outs[0][1], outs[1][1], 2e-3, "halo vs gather stats")
+    close(outs[0][0], outs[1][0], 4e-3, "lds / halo vs gather out")
+    close(outs[0][1], outs[1][1], 2e-3, "lds / halo vs gather stats")
+    close(outs[2][0], outs[1][0], 4e-3, "halo vs gather out")
+    close(outs[2][1], outs[1][1], 2e-3, "halo vs gather stats")
 
 
 @pytest.mark.parametrize("Cin,Cout,Hh,Ww,N,aff,relu,res,mask,events", [

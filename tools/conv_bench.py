@@ -13,6 +13,7 @@ iters = int(sys.argv[9]) if len(sys.argv) > 9 else 20
 aff = int(os.environ.get("CB_AFF", "0"))
 res = int(os.environ.get("CB_RES", "0"))          # 0 none, 1 same-res, 2 upsampled (half-res operand), 3 pooled (double-res operand)
 want_stats = int(os.environ.get("CB_STATS", "1"))
+flags = int(os.environ.get("CB_FLAGS", "0"))       # 1: force gather kernel, 2: conv3x3_halo instead of conv3x3_lds
 H.require_gpu()
 dev = "cuda:0"
 x = torch.randn(N, Hh, Ww, Cin, device=dev).to(torch.bfloat16)
@@ -35,7 +36,7 @@ elif res == 3:
 
 def run():
     ops._conv_launch(x, Cin, Hh, Ww, 0, sc, sh, Cin if aff else 0, bool(relu), N, Hh, Ww, Cin, Cout, taps, kpad, w, bias, ra, Cout if ra is not None else 0,
-                     Cout if ra is not None else 0, max(res - 1, 0), None, 0, mk, out, stats)
+                     Cout if ra is not None else 0, max(res - 1, 0), None, 0, mk, out, stats, flags=flags)
 
 
 for _ in range(3):
@@ -50,4 +51,4 @@ torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3 / iters
 flops = 2.0 * N * Hh * Ww * Cout * taps * Cin
 byts = 2.0 * N * Hh * Ww * (Cin + Cout * (2 if mask else 1))
-print(f"conv {taps}tap N{N} {Hh}x{Ww} {Cin}->{Cout} relu{relu} mask{mask} aff{aff} res{res} stats{want_stats}: {us:.1f} us  {flops/us/1e6:.0f} TF  {byts/us/1e3:.0f} GB/s")
+print(f"conv {taps}tap N{N} {Hh}x{Ww} {Cin}->{Cout} relu{relu} mask{mask} aff{aff} res{res} stats{want_stats} flags{flags}: {us:.1f} us  {flops/us/1e6:.0f} TF  {byts/us/1e3:.0f} GB/s")
