@@ -38,7 +38,7 @@ class ConvDesc(C.Structure):
 class WgradDesc(C.Structure):
     _fields_ = [("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
                 ("taps", C.c_int), ("Kpad", C.c_int), ("src", SrcDesc), ("g", vp), ("Cg", C.c_int),
-                ("dw", vp), ("tiles_per_block", C.c_int), ("colsum", vp)]
+                ("dw", vp), ("tiles_per_block", C.c_int), ("pad_rows", C.c_int), ("partials", vp), ("colsum", vp)]
 
 
 class ProfRec(C.Structure):
@@ -46,7 +46,7 @@ class ProfRec(C.Structure):
                 ("flops", C.c_double), ("bytes", C.c_double), ("bytes_min", C.c_double)]
 
 
-ABI_VERSION = 4            # include/ieagan_hip.h: IEAGAN_ABI_VERSION
+ABI_VERSION = 6            # include/ieagan_hip.h: IEAGAN_ABI_VERSION
 i, f, l = C.c_int, C.c_float, C.c_long
 _SIGS = {
     "ieagan_abi_version": [],
@@ -55,6 +55,7 @@ _SIGS = {
     "ieagan_prof_collect": [C.POINTER(ProfRec), i],
     "ieagan_conv_forward": [C.POINTER(ConvDesc), vp],
     "ieagan_conv_wgrad": [C.POINTER(WgradDesc), i, vp],
+    "ieagan_conv_wgrad_workspace": [C.POINTER(WgradDesc), i],
     "ieagan_effgrad": [vp, vp, vp, vp, vp, l, i, i, vp],
     "ieagan_prologue_bwd": [vp, vp, i, vp, vp, i, i, i, vp, vp, vp, i, i, i, i, vp, i, i, i, vp],
     "ieagan_bn_finalize_fwd": [vp, f, vp, vp, i, i, f, f, i, vp, vp, vp, vp, vp, i, i, i, vp],
@@ -113,7 +114,7 @@ def lib():
         for name, sig in _SIGS.items():
             fn = getattr(_lib, name)
             fn.argtypes = sig
-            fn.restype = C.c_int
+            fn.restype = C.c_long if name.endswith("_workspace") else C.c_int
     return _lib
 
 

@@ -194,3 +194,46 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x4 (&a
     __builtin_amdgcn_wave_barrier();                             // anything that touches ANOTHER wave's region needs a block barrier
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// A-operand gather with the fused prologue: 8 consecutive channels [c, c+8) of the (virtual) conv-input pixel (n, hh, ww) at
+// conv resolution; zero outside the image (conv padding is applied AFTER the activation, as in the reference).
+// ------------------------------------------------------------------------------------------------
+template <bool AFF, bool RELU, int RS>
+__device__ __forceinline__ bf16x8 gather8(const SrcDesc& s, int H, int W, int n, int hh, int ww, int c, bool ok,
+                                          const float* aff = nullptr) {
+    ok = ok && (hh >= 0) && (hh < H) && (ww >= 0) && (ww < W);
+    if (!ok) return zero8();
+    if (RS == 2) {  // conv pixel = mean of the 2x2 source block (AvgPool2d(2) of the activated source)
+        float acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bf16x8 raw = *(const bf16x8*)((const bf16*)s.x + (((long)n * s.Hs + 2 * hh + (q >> 1)) * s.Ws + 2 * ww + (q & 1)) * s.Cx + c);
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = bf2f(raw[i]);
+            xform8<AFF, RELU>(v, s, n, c, aff);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += v[i];
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = f2bf(0.25f * acc[i]);
+        return o;
+    }
+    const int sh_ = (RS == 1) ? (hh >> 1) : hh, sw_ = (RS == 1) ? (ww >> 1) : ww;
+    const bf16x8 raw = *(const bf16x8*)((const bf16*)s.x + (((long)n * s.Hs + sh_) * s.Ws + sw_) * s.Cx + c);
+    if (!AFF && !RELU) return raw;
+    if (!AFF && RELU) return relu8(raw);
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = bf2f(raw[i]);
+    xform8<AFF, RELU>(v, s, n, c, aff);
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = f2bf(v[i]);
+    return o;
+}
+

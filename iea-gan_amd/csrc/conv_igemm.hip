@@ -22,44 +22,6 @@
 // conv-input pixel (n, hh, ww) at conv resolution; zero outside the image (conv padding is applied
 // AFTER the activation, as in the reference where the activated tensor is what gets padded).
 // ------------------------------------------------------------------------------------------------
-template <bool AFF, bool RELU, int RS>
-__device__ __forceinline__ bf16x8 gather8(const SrcDesc& s, int H, int W, int n, int hh, int ww, int c, bool ok,
-                                          const float* aff = nullptr) {
-    ok = ok && (hh >= 0) && (hh < H) && (ww >= 0) && (ww < W);
-    if (!ok) return zero8();
-    if (RS == 2) {  // conv pixel = mean of the 2x2 source block (AvgPool2d(2) of the activated source)
-        float acc[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const bf16x8 raw = *(const bf16x8*)((const bf16*)s.x + (((long)n * s.Hs + 2 * hh + (q >> 1)) * s.Ws + 2 * ww + (q & 1)) * s.Cx + c);
-            float v[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = bf2f(raw[i]);
-            xform8<AFF, RELU>(v, s, n, c, aff);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] += v[i];
-        }
-        bf16x8 o;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = f2bf(0.25f * acc[i]);
-        return o;
-    }
-    const int sh_ = (RS == 1) ? (hh >> 1) : hh, sw_ = (RS == 1) ? (ww >> 1) : ww;
-    const bf16x8 raw = *(const bf16x8*)((const bf16*)s.x + (((long)n * s.Hs + sh_) * s.Ws + sw_) * s.Cx + c);
-    if (!AFF && !RELU) return raw;
-    if (!AFF && RELU) return relu8(raw);
-    float v[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = bf2f(raw[i]);
-    xform8<AFF, RELU>(v, s, n, c, aff);
-    bf16x8 o;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = f2bf(v[i]);
-    return o;
-}
-
 // ------------------------------------------------------------------------------------------------
 // conv_gather: block = 4 waves, each wave 2 m-tiles (32 pixels) x NT n-tiles (16*NT channels);
 // A fragments gathered straight from global memory (any H, W; 1x1 and small 3x3 layers).
@@ -594,213 +556,3 @@ int conv_gather_launch(const ConvArgs& a, hipStream_t st) {
     return rc;
 }
 
-// ------------------------------------------------------------------------------------------------
-// conv_wgrad
-// ------------------------------------------------------------------------------------------------
-#define WG_TH 8
-#define WG_TW 16
-
-// 8 K(pixel)-consecutive values of one column, from a [rows][cols] 16-bit LDS image.
-// TR: two ds_read_b64_tr_b16 (lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3 and
-// receives column (lane&15) of the 4 rows).  !TR: eight scalar reads (reference path for the test).
-template <bool TR>
-__device__ __forceinline__ bf16x8 frag_T(const bf16* lds, int row0_bytes_unused, int stride_elems, int pix0, int col0, int lr) {
-    bf16x8 f;
-    if (TR) {
-        const int q = lr >> 2, p = lr & 3;
-        const bf16* p0 = lds + (pix0 + q) * stride_elems + col0 + 4 * p;
-        const bf16* p1 = p0 + 4 * stride_elems;
-        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)p0);
-        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)p1);
-        f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
-        f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
-    } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = lds[(pix0 + j) * stride_elems + col0 + lr];
-    }
-    return f;
-}
-
-template <int TAPS, bool AFF, bool RELU, int RS, int MT, bool TR, int NJ>
-__global__ __launch_bounds__(256, (TR ? (MT == 4 ? 3 : (MT == 8 ? 2 : 1)) : 1)) void conv_wgrad_kernel(WgradArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int HALO = (TAPS == 9) ? 1 : 0;
-    constexpr int AW = WG_TW + 2 * HALO, AH = WG_TH + 2 * HALO;
-    const int GC = MT * 16;                       // cout columns of the g tile
-    bf16* lds_g = (bf16*)smem;                    // [WG_TH*WG_TW][GC]
-    bf16* lds_a = lds_g + WG_TH * WG_TW * GC;     // [AH*AW][Cin]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int lr = lane & 15, lg = lane >> 4;
-    const int H = a.H, W = a.W, Cin = a.Cin;
-    const int tiles_w = (W + WG_TW - 1) / WG_TW, tiles_h = (H + WG_TH - 1) / WG_TH;
-    const int tiles_img = tiles_w * tiles_h;
-    const long tiles_total = (long)a.N * tiles_img;
-    const int cout0 = blockIdx.z * GC;
-    const int cin_tiles = Cin >> 4;
-    const int nt_total = TAPS * cin_tiles;
-
-    // this wave's 4 n-tiles: (tap, cin0); invalid ones are clamped for addressing and skipped at the end
-    int t_dy[4], t_dx[4], t_c0[4], t_kcol[4];
-    bool t_ok[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int ntg = blockIdx.y * 16 + j * 4 + wave;          // round-robin: 9 n-tiles (3x3, C=16) -> 3/2/2/2 per wave
-        t_ok[j] = ntg < nt_total;
-        const int q = t_ok[j] ? ntg : 0;
-        const int tap = q / cin_tiles;
-        t_c0[j] = (q - tap * cin_tiles) * 16;
-        t_dy[j] = (TAPS == 9) ? tap / 3 : 0;          // already offset by +HALO-1 (dy-1+1)
-        t_dx[j] = (TAPS == 9) ? tap - (tap / 3) * 3 : 0;
-        t_kcol[j] = tap * Cin + t_c0[j];
-    }
-    f32x4 acc[MT][4];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const bool do_colsum = a.colsum != nullptr && blockIdx.y == 0;      // one n-tile group per (pixel, cout) tile does it
-    float csum = 0.f;
-    const long tile_begin = (long)blockIdx.x * a.tiles_per_block;
-    long tile_end = tile_begin + a.tiles_per_block;
-    if (tile_end > tiles_total) tile_end = tiles_total;
-    for (long tile = tile_begin; tile < tile_end; ++tile) {
-        const int n = (int)(tile / tiles_img);
-        const int tr_ = (int)(tile - (long)n * tiles_img);
-        const int h0 = (tr_ / tiles_w) * WG_TH, w0 = (tr_ % tiles_w) * WG_TW;
-        __syncthreads();   // previous tile's fragments consumed
-        // ---- stage g tile: 128 pixels x GC couts, 16-byte chunks
-        for (int idx = threadIdx.x; idx < WG_TH * WG_TW * (GC / 8); idx += 256) {
-            const int px = idx / (GC / 8), cc = idx - px * (GC / 8);
-            const int hh = h0 + px / WG_TW, ww = w0 + px % WG_TW;
-            bf16x8 v = zero8();
-            if (hh < H && ww < W && cout0 + cc * 8 < a.Cout) v = *(const bf16x8*)((const bf16*)a.g + (((long)n * H + hh) * W + ww) * a.Cg + cout0 + cc * 8);
-            *(bf16x8*)(lds_g + px * GC + cc * 8) = v;
-        }
-        // ---- stage a tile (+halo) with the fused prologue
-        for (int idx = threadIdx.x; idx < AH * AW * (Cin / 8); idx += 256) {
-            const int hp = idx / (Cin / 8), cc = idx - hp * (Cin / 8);
-            const int hh = h0 - HALO + hp / AW, ww = w0 - HALO + hp % AW;
-            const bf16x8 v = gather8<AFF, RELU, RS>(a.src, H, W, n, hh, ww, cc * 8, true);
-            *(bf16x8*)(lds_a + hp * Cin + cc * 8) = v;
-        }
-        __syncthreads();
-        if (do_colsum) {      // bias gradient: column sums of the staged g tile (thread = column t % GC, pixel phase t / GC)
-            for (int px = threadIdx.x / GC; px < WG_TH * WG_TW; px += 256 / GC) csum += bf2f(lds_g[px * GC + (threadIdx.x % GC)]);
-        }
-        // ---- 4 k-steps of 32 pixels (two tile rows each); lane group lg owns 8 consecutive pixels
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int row = 2 * ks + (lg >> 1), col = (lg & 1) * 8;
-            bf16x8 af[MT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) af[mt] = frag_T<TR>(lds_g, 0, GC, row * WG_TW + col, mt * 16, lr);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {          // NJ = 1: layers with <= 4 n-tiles in total (1x1, Cin <= 64): one per wave
-                const bf16x8 bfr = frag_T<TR>(lds_a, 0, Cin, (row + t_dy[j]) * AW + col + t_dx[j], t_c0[j], lr);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfr, acc[mt][j], 0, 0, 0);
-            }
-        }
-    }
-    if (do_colsum) {          // fold the 256 / GC pixel phases of a column through LDS, one atomic per column per block
-        __syncthreads();
-        float* red = (float*)smem;
-        red[threadIdx.x] = csum;
-        __syncthreads();
-        if (threadIdx.x < GC && cout0 + threadIdx.x < a.Cout) {
-            float t = 0.f;
-            for (int ph = 0; ph < 256 / GC; ++ph) t += red[ph * GC + threadIdx.x];
-            atomicAdd(a.colsum + (long)(blockIdx.x % STAT_REPL) * a.Cout + cout0 + threadIdx.x, t);
-        }
-    }
-    // ---- accumulate into dWp[cout][k]
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        if (!t_ok[j]) continue;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (cout0 + mt * 16 + lg * 4 + r < a.Cout)
-                    atomicAdd(a.dw + (long)(cout0 + mt * 16 + lg * 4 + r) * a.Kpad + t_kcol[j] + lr, acc[mt][j][r]);
-    }
-}
-
-template <int TAPS, bool AFF, bool RELU, int RS, bool TR>
-static void launch_wgrad_mt(const WgradArgs& a, hipStream_t st, int mt, dim3 grid, size_t lds) {
-    const bool one = TAPS == 1 && TR && a.Cin <= 64;       // <= 4 n-tiles in total: every wave owns at most one
-#define WG_L(MTV)                                                                                                       \
-    {                                                                                                                   \
-        if (TAPS == 1 && TR && one) hipLaunchKernelGGL((conv_wgrad_kernel<TAPS, AFF, RELU, RS, MTV, TR, (TAPS == 1 && TR) ? 1 : 4>), grid, dim3(256), lds, st, a); \
-        else hipLaunchKernelGGL((conv_wgrad_kernel<TAPS, AFF, RELU, RS, MTV, TR, 4>), grid, dim3(256), lds, st, a);     \
-    }
-    switch (mt) {
-        case 1: WG_L(1) break;
-        case 2: WG_L(2) break;
-        case 4: WG_L(4) break;
-        default: WG_L(8) break;
-    }
-#undef WG_L
-}
-
-template <int TAPS, int RS, bool TR>
-static void launch_wgrad_pro(const WgradArgs& a, hipStream_t st, int mt, dim3 grid, size_t lds) {
-    const bool aff = a.src.scale != nullptr, relu = a.src.relu != 0;
-    if (aff && relu) launch_wgrad_mt<TAPS, true, true, RS, TR>(a, st, mt, grid, lds);
-    else if (aff) launch_wgrad_mt<TAPS, true, false, RS, TR>(a, st, mt, grid, lds);
-    else if (relu) launch_wgrad_mt<TAPS, false, true, RS, TR>(a, st, mt, grid, lds);
-    else launch_wgrad_mt<TAPS, false, false, RS, TR>(a, st, mt, grid, lds);
-}
-
-int conv_wgrad_launch(const WgradArgs& a0, hipStream_t st, int use_tr) {
-    WgradArgs a = a0;
-    CHECK_ARG(a.taps == 1 || a.taps == 9, "wgrad: taps must be 1 or 9");
-    CHECK_ARG(a.Cin % 16 == 0 && a.Cout % 8 == 0, "wgrad: Cin %% 16 and Cout %% 8 required (%d,%d)", a.Cin, a.Cout);
-    CHECK_ARG(a.Kpad >= a.taps * a.Cin, "wgrad: bad Kpad");
-    CHECK_ARG(a.Cg >= a.Cout && a.Cg % 8 == 0, "wgrad: bad g channel stride %d", a.Cg);
-    if (a.src.rs == 1) CHECK_ARG(a.H == 2 * a.src.Hs && a.W == 2 * a.src.Ws, "wgrad: upsample geometry mismatch");
-    if (a.src.rs == 2) CHECK_ARG(2 * a.H == a.src.Hs && 2 * a.W == a.src.Ws, "wgrad: pool geometry mismatch");
-    if (a.src.rs == 0) CHECK_ARG(a.H == a.src.Hs && a.W == a.src.Ws, "wgrad: geometry mismatch");
-    // cout chunking: MT m-tiles per block (<= 8)
-    int mt = 8;
-    if (a.Cout % 128 != 0) mt = (a.Cout % 64 == 0) ? 4 : (a.Cout % 32 == 0) ? 2 : 1;
-    const int gz = (a.Cout + mt * 16 - 1) / (mt * 16);
-    const int nt_total = a.taps * (a.Cin / 16);
-    const int gy = (nt_total + 15) / 16;
-    const long tiles = (long)a.N * ((a.H + WG_TH - 1) / WG_TH) * ((a.W + WG_TW - 1) / WG_TW);
-    // Every block ends with one float atomicAdd per owned dW element, and the chip retires only ~1.3 TB/s of atomics:
-    // the larger dW is, the fewer pixel splits pay off (measured optimum per layer size on MI355X).
-    const long dw_elems = (long)a.Cout * a.taps * a.Cin;
-    const long blocks_goal = dw_elems <= 4096 ? 2048 : dw_elems <= 12288 ? 1024 : (dw_elems <= 65536 || tiles > 128) ? 512 : 256;
-    long target = blocks_goal / (gy * gz);
-    if (target < 64) target = 64;
-    int tpb = (int)((tiles + target - 1) / target);
-    if (tpb < 1) tpb = 1;
-    a.tiles_per_block = tpb;
-    const int gx = (int)((tiles + tpb - 1) / tpb);
-    const int halo = (a.taps == 9) ? 1 : 0;
-    const size_t lds = (size_t)WG_TH * WG_TW * mt * 16 * 2 + (size_t)(WG_TH + 2 * halo) * (WG_TW + 2 * halo) * a.Cin * 2;
-    CHECK_ARG(lds <= 160 * 1024, "wgrad: LDS request %zu too large", lds);
-    const double flops = 2.0 * a.N * a.H * a.W * (double)a.Cout * a.taps * a.Cin;
-    const double bytes = 2.0 * a.N * ((double)a.src.Hs * a.src.Ws * a.Cin + (double)a.H * a.W * a.Cout);
-    char tag[64] = "";
-    if (prof_tags_on()) snprintf(tag, sizeof(tag), "ci%d co%d %dx%d rs%d grid%dx%dx%d", a.Cin, a.Cout, a.H, a.W, a.src.rs, gx, gy, gz);
-    ProfScope prof(a.taps == 9 ? "conv3x3_wgrad" : "conv1x1_wgrad", flops, bytes, st, tag);
-    dim3 grid(gx, gy, gz);
-#define WG_DISPATCH(TR)                                                                  \
-    if (a.taps == 9) {                                                                   \
-        if (a.src.rs == 0) launch_wgrad_pro<9, 0, TR>(a, st, mt, grid, lds);             \
-        else if (a.src.rs == 1) launch_wgrad_pro<9, 1, TR>(a, st, mt, grid, lds);        \
-        else { ieagan_set_error("wgrad: 3x3 with pooled source not instantiated"); return IEAGAN_EINVAL; } \
-    } else {                                                                             \
-        if (a.src.rs == 0) launch_wgrad_pro<1, 0, TR>(a, st, mt, grid, lds);             \
-        else if (a.src.rs == 2) launch_wgrad_pro<1, 2, TR>(a, st, mt, grid, lds);        \
-        else { ieagan_set_error("wgrad: 1x1 with upsampled source not instantiated"); return IEAGAN_EINVAL; } \
-    }
-    if (use_tr) { WG_DISPATCH(true) } else { WG_DISPATCH(false) }
-#undef WG_DISPATCH
-    CHECK_LAUNCH("conv_wgrad");
-    return 0;
-}

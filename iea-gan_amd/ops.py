@@ -168,6 +168,7 @@ class SNBank:
 
     def __init__(self, arena: torch.Tensor, entries, stack=(), owner=None, biases=None):
         self.arena = arena
+        self._prefetched = []
         self.owner, self.bwd = owner, None          # owner: the network's Arena (flat gradient buffer) -> batched backward
         self.names = [e[0] for e in entries]
         self.index = {n: i for i, n in enumerate(self.names)}
@@ -257,14 +258,49 @@ class SNBank:
         self.bwd = dict(rows={k: tuple(v) for k, v in rows.items()}, total=goff, nwork=len(work),
                         table=torch.tensor(tab, dtype=torch.int64, device=dev), work=torch.tensor(work, dtype=torch.int32, device=dev))
 
-    def run(self, training: bool, eps: float):
+    def _launch(self, training: bool, eps: float):
         dev = self.arena.device
         ctx = torch.empty(self.ctx_size, dtype=torch.float32, device=dev)
         part = torch.empty(self.part_size, dtype=torch.float32, device=dev)
         pack = torch.empty(self.pack_size, dtype=torch.uint8, device=dev)
-        H.call("ieagan_sn_forward", self.table.data_ptr(), self.blocks.data_ptr(), self.nblocks, self.cblocks.data_ptr(),
-               self.ncblocks, self.arena.data_ptr(), ctx.data_ptr(), part.data_ptr(), pack.data_ptr(), float(eps),
-               int(training), H.stream())
+
+        def go():
+            H.call("ieagan_sn_forward", self.table.data_ptr(), self.blocks.data_ptr(), self.nblocks, self.cblocks.data_ptr(),
+                   self.ncblocks, self.arena.data_ptr(), ctx.data_ptr(), part.data_ptr(), pack.data_ptr(), float(eps),
+                   int(training), H.stream())
+        return (ctx, part, pack), go
+
+    def prefetch(self, training: bool, eps: float, side):
+        """Issue the power iteration of the NEXT forward pass of this network on the stream ``side`` now.  The spectral norms
+        depend on the weights only, never on activations: one pass (~0.2 ms of small launches that leave most CUs idle) can run
+        under the convolutions of whatever the main stream is doing.  Passes queue in order (every pass advances ``u``); the
+        next ``run`` call hands out the oldest one after making the current stream wait for it.  The result buffers are
+        allocated on the current stream, which is also where they are consumed and released."""
+        main = torch.cuda.current_stream()
+        bufs, go = self._launch(training, eps)
+        ready = torch.cuda.Event()
+        ready.record(main)                     # weights as of now (e.g. behind the optimizer step)
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            go()
+            done = torch.cuda.Event()
+            done.record(side)
+        self._prefetched.append((bool(training), float(eps), bufs, done))
+
+    def discard_prefetched(self):
+        """Drop queued passes (a step that ended early); the main stream still joins them."""
+        while self._prefetched:
+            torch.cuda.current_stream().wait_event(self._prefetched.pop(0)[3])
+
+    def run(self, training: bool, eps: float):
+        if self._prefetched:
+            tr, e, (ctx, part, pack), done = self._prefetched.pop(0)
+            if tr != bool(training) or e != float(eps):
+                raise RuntimeError("a prefetched spectral-norm pass was issued for a different mode than the forward that consumes it")
+            torch.cuda.current_stream().wait_event(done)
+        else:
+            (ctx, part, pack), go = self._launch(training, eps)
+            go()
         recs = {}
         ps = SNPass(self, ctx)
         for n, (kind, out, inn, taps, cin, kpad, kpad2, coff, p1, p2) in zip(self.names, self.meta):
@@ -478,6 +514,7 @@ def _conv_launch(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu, N, Hc, Wc, Cin,
 
 
 USE_TR_READ = True        # ds_read_b64_tr_b16 operand reads in conv_wgrad (False: scalar LDS reads)
+TWO_STAGE_WGRAD = False   # conv_wgrad: partial slabs + reduction launch instead of float atomics when the atomic volume is large
 FUSE_BN_BACKWARD = True   # BatchNorm-apply backward inside the dgrad epilogue (False: the stand-alone prologue_bwd pass)
 
 
@@ -668,8 +705,14 @@ class ConvFn(torch.autograd.Function):
         if need[1]:
             dwp = sn_scratch(rec, "w", (Cout, rec.kpad), dev)
             d = H.WgradDesc(N, Hc, Wc, Cin, Cout, taps, rec.kpad,
-                            H.src_desc(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu), g.data_ptr(), Cg, dwp.data_ptr(), 0,
+                            H.src_desc(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu), g.data_ptr(), Cg, dwp.data_ptr(), 0, 0, None,
                             H.ptr(colsum) if colsum_in_wgrad else None)
+            # large weight x many pixel splits: the blocks store partial slabs and a second launch folds them (two-stage
+            # accumulation; the float-atomic tail was the longest phase of these launches)
+            ws_n = H.lib().ieagan_conv_wgrad_workspace(d, int(USE_TR_READ)) if TWO_STAGE_WGRAD else 0
+            if ws_n > 0:
+                ws = torch.empty(ws_n, dtype=torch.float32, device=dev)
+                d.partials = ws.data_ptr()
             H.call("ieagan_conv_wgrad", d, int(USE_TR_READ), H.stream())
             dW, dbias = sn_backward(dwp, weight, rec, colsum if (has_bias and need[2]) else None, ctx.bias_ref)
         elif has_bias and need[2]:

@@ -152,10 +152,27 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
             terms = tm if terms is None else terms + tm
         return total / float(E), terms / float(E)
 
+    # Spectral-norm passes ahead of time on a side stream (ops.SNBank.prefetch): 4 of the 5 passes of a step depend on weights
+    # that are final long before the forward that consumes them.  Single-GPU default step only (split_D, no accumulation): the
+    # number of forward passes per phase is then known -- G: 1 + 1, D: 2 (+1 with Con_reg) + 1.
+    sn_ahead = bool(config.get("sn_prefetch", True)) and sync is None and config["split_D"] and config["num_D_steps"] == 1 and \
+        config["num_D_accumulations"] == 1 and config["num_G_accumulations"] == 1 and contra
+
+    def prefetch_sn(net, passes):
+        if not sn_ahead or not next(net.parameters()).is_cuda:
+            return
+        if st.get("sn_stream") is None:
+            st["sn_stream"] = torch.cuda.Stream()
+        bank = net._prepare()["bank"]
+        for _ in range(passes):
+            bank.prefetch(net.training, net.SN_eps, st["sn_stream"])
+
     # ------------------------------------------------------------------------------------------------ D phase
     def d_forward_backward():
         """Zero both gradient arenas, accumulate D's gradient (train_fns.py:24-130); returns [real, fake, unif_d]."""
         x, y = st["x"], st["y"]
+        prefetch_sn(G, 2)                       # both generator passes of the step: G's weights only change in g_update
+        prefetch_sn(D, 3 if config["Con_reg"] else 2)      # D(fake), D(real)[, D(real_aug)]: D's weights change in d_update
         G.optim.zero_grad()
         D.optim.zero_grad()
         x_aug = None
@@ -288,6 +305,8 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
                 sync.wait("G")          # likewise G's update of the previous step (it zeroes / reads G's gradient arena)
             dv = run_d()
             reduce(D, "D", d_update)
+            if not replayed:
+                prefetch_sn(D, 1)               # the G-phase discriminator pass sees the updated weights: overlaps G's forward
         if replayed and sync is not None:
             sync.wait("D")
         gv = run_g()

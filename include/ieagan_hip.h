@@ -19,7 +19,7 @@ extern "C" {
 #endif
 
 const char* ieagan_last_error(void);
-#define IEAGAN_ABI_VERSION 4        /* bumped whenever a struct layout or a signature in this header changes */
+#define IEAGAN_ABI_VERSION 6        /* bumped whenever a struct layout or a signature in this header changes */
 int ieagan_abi_version(void);        /* == IEAGAN_ABI_VERSION of the header the library was built from */
 
 /* ---- profiling hooks (bench.py): per-kernel HIP-event timing on the launch stream ---- */
@@ -93,10 +93,16 @@ typedef struct {
     int Cg;
     float* dw;            /* fp32 [Cout][Kpad], caller zeroes                                   */
     int tiles_per_block;  /* filled by the launcher                                             */
+    int pad_rows;         /* filled by the launcher                                             */
+    float* partials;      /* optional workspace of ieagan_conv_wgrad_workspace(d) floats: the pixel-split blocks then STORE
+                           * their partial dW slabs there and a second launch folds them into dw -- float atomics retire at
+                           * ~0.7 TB/s here, which made the accumulation tail the longest phase of every large-dW launch */
     float* colsum;        /* optional fp32 [32][Cout], caller-zeroed replicas: += column sums of g (the
                            * bias gradient), taken from the g tiles the kernel stages anyway           */
 } ieagan_wgrad_desc;
 int ieagan_conv_wgrad(const ieagan_wgrad_desc* d, int use_tr_read, void* stream);
+/* floats of `partials` workspace the launch can use (0: the direct atomic accumulation is the better choice) */
+long ieagan_conv_wgrad_workspace(const ieagan_wgrad_desc* d, int use_tr_read);
 
 /* ---- element-wise companions (bn_elem.hip) ---------------------------------------------------- */
 /* g_eff = dout + dsum[e][c] + 2*out*dsumsq[e][c]; colsum[32][C] += column sums (bias gradient).

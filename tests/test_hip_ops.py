@@ -358,7 +358,7 @@ def test_wgrad_tr_vs_scalar_reads(dev):
     outs = []
     for tr in (1, 0):
         dw = torch.zeros(Cout, 9 * Cin, device=dev)
-        d = _hip.WgradDesc(N, Hh, Ww, Cin, Cout, 9, 9 * Cin, _hip.src_desc(x, Cin, Hh, Ww), g.data_ptr(), Cout, dw.data_ptr(), 0)
+        d = _hip.WgradDesc(N, Hh, Ww, Cin, Cout, 9, 9 * Cin, _hip.src_desc(x, Cin, Hh, Ww), g.data_ptr(), Cout, dw.data_ptr(), 0, 0, None)
         _hip.call("ieagan_conv_wgrad", d, tr, _hip.stream())
         outs.append(dw)
     ref = torch.nn.grad.conv2d_weight(nchw(x), (Cout, Cin, 3, 3), nchw(g), padding=1)
