@@ -1,6 +1,6 @@
 """HBM traffic per kernel family from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of the same bench command.
 
-usage: python profiles/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <steps> <out.json>
+usage: python profiles/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <steps> <out.json> [git head]
 
 bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: the counters tick in KiB and gfx950's FETCH_SIZE counts half of wide
 coalesced reads (MI355X_MICROARCH.md, HBM / rocprofv3 section).  Families are the names bench.py's per-kernel HIP-event
@@ -12,7 +12,9 @@ from collections import defaultdict
 
 def family(name):
     n = re.sub(r"^void ", "", name)
-    if n.startswith("conv_gather_kernel<1"): return "conv1x1_gather"
+    if n.startswith("conv_gather_kernel<1") or n.startswith("conv1x1_stream_kernel"): return "conv1x1_gather"      # (bench.py family names)
+    if n.startswith("conv3x3_lds_kernel"): return "conv3x3_halo"
+    if n.startswith("wgrad_reduce_kernel"): return "conv3x3_wgrad"
     if n.startswith("conv_gather_kernel<9"): return "conv3x3_gather"
     if n.startswith("conv3x3_halo_kernel"): return "conv3x3_halo"
     if n.startswith("conv_wgrad_kernel<9"): return "conv3x3_wgrad"
@@ -50,9 +52,10 @@ def main():
         n = max(nf.get(f, 0), nw.get(f, 0), 1)
         fams[f] = {"launches_per_step": n / steps, "hbm_GB_per_step": b / steps / 1e9, "hbm_bytes_per_launch": b / n}
     total = sum(v["hbm_GB_per_step"] for v in fams.values())
+    head = sys.argv[5] if len(sys.argv) > 5 else None
     json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of the same bench.py command; "
                        "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md",
-               "steps": steps, "hbm_GB_per_step_total": total, "families": fams}, open(out, "w"), indent=1)
+               "git_head": head, "steps": steps, "hbm_GB_per_step_total": total, "families": fams}, open(out, "w"), indent=1)
     print(f"{total:.1f} GB/step over {len(fams)} families -> {out}")
 
 
