@@ -19,7 +19,7 @@ One JSON line on stdout (rank 0):
 * ``families``: every family with its HBM and MFMA fractions.
 * ``cpu_baseline``: the CPU oracle (plain PyTorch restatement of the reference step, oracle/) timed on this host.
 * ``configs3`` (N = 1, unless --no-configs3): the same measurement for BASELINE configs[3] -- 4 events per GPU and step with
-  DiffAugment + CR_DiffAug consistency regularisation + uniformity loss.
+  DiffAugment + CR_DiffAug consistency regularisation + uniformity loss; ``configs4``: configs[1] with the fp8 conv path.
 """
 import argparse
 import contextlib
@@ -62,8 +62,10 @@ def bench_config(which=1):
     cfg.update(device="cuda", clip_norm=1e9)
     if which == 1:      # configs[1]: hinge loss only, RRM on
         cfg.update(contra_lambda=0.0, IEA_loss=False, Uniformity_loss=False)
-    else:               # configs[3]: 4 events/GPU, diff_aug + cr_diff_aug + uniformity loss (full default loss composition)
+    elif which == 3:    # configs[3]: 4 events/GPU, diff_aug + cr_diff_aug + uniformity loss (full default loss composition)
         cfg.update(events_per_step=4, Con_reg=True, diff_aug=True, Uniformity_loss=True)
+    else:               # configs[4]: configs[1] with e4m3 MFMA operands in the forward of the C >= 64 3x3 layers
+        cfg.update(contra_lambda=0.0, IEA_loss=False, Uniformity_loss=False, conv_dtype="fp8")
     return cfg
 
 
@@ -354,6 +356,13 @@ def main():
         if m3["recs"]:
             kernel_report(r3, m3, args)
         res["configs3"] = r3
+        m4 = measure(cfg_for(4), argparse.Namespace(**dict(vars(args), no_kernel_timing=True)), rank, world, local, "configs4")
+        res["configs4"] = {"workload": "BASELINE configs[4] on ONE GPU: configs[1] with OCP e4m3 MFMA operands (per-slice weight scale, per-tile "
+                                       "activation scale, fp32 accumulate) in the forward C >= 64 3x3 convolutions; tensors in HBM stay bf16, "
+                                       "dgrad / wgrad bf16.  Non-scaled fp8 MFMA runs at the bf16 rate on gfx950: a precision / footprint "
+                                       "variant, not a faster one", "value": m4["E"] * m4["steps"] / m4["dt"], "unit": "events/s",
+                           "steps": m4["steps"], "ms_per_step": 1e3 * m4["dt"] / m4["steps"], "dtype": "fp8 (e4m3) operands / bf16 tensors",
+                           "losses_last_step": m4["out"], "tolerance": "tests/test_networks_gpu.py::test_fp8_conv_path_forward_and_step_tolerance"}
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(cfg_for(1), args.cpu_baseline)
     print(json.dumps(res))

@@ -22,14 +22,15 @@
 // bits with key = (r >> 1) & 7;  CPR % 16 == 0 -> permute 4 bits with key = r & 15.  `r` only has to enumerate the 16 rows of
 // a fragment read bijectively: the weight image uses the row index, the halo image the COLUMN of the pixel inside its halo row
 // (16 consecutive pixels of a row), which keeps every read address = per-lane register + compile-time immediate.
+// (CPR % 16 == 4, the fp8 images of 64-channel rows: two row bits select a quarter of the slots, key = (r >> 2) & 3 permutes 2 bits.)
 template <int CPR>
 __device__ __forceinline__ int swz_key(int r) {
-    static_assert(CPR % 16 == 8 || CPR % 16 == 0, "swizzle derived for rows of 8 or 16 (mod 16) chunks");
-    return (CPR % 16 == 8) ? ((r >> 1) & 7) : (r & 15);
+    static_assert(CPR % 16 == 8 || CPR % 16 == 0 || CPR % 16 == 4, "swizzle derived for rows of 4, 8 or 16 (mod 16) chunks");
+    return (CPR % 16 == 8) ? ((r >> 1) & 7) : (CPR % 16 == 4 ? ((r >> 2) & 3) : (r & 15));
 }
 template <int CPR>
 __device__ __forceinline__ int swz(int key, int chunk) {
-    constexpr int G = (CPR % 16 == 8) ? 8 : 16;
+    constexpr int G = (CPR % 16 == 8) ? 8 : (CPR % 16 == 4 ? 4 : 16);
     return (chunk & ~(G - 1)) | ((chunk ^ key) & (G - 1));
 }
 
@@ -244,11 +245,310 @@ static int lds_launch(const ConvArgs& a, hipStream_t st) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// fp8 variant (BASELINE configs[4]): the same layers with OCP e4m3 MFMA operands (v_mfma_f32_16x16x32_fp8_fp8), fp32 accumulate.
+//   * scales: one per BLOCK weight slice (amax over its NT*16 x 9*CIN weights) and one per TILE of activations (amax over the
+//     transformed halo), both mapped to 224 = half of e4m3's largest finite value; the accumulators are rescaled by
+//     1 / (s_w * s_a) before the epilogue.  Finer than per-tensor scales and needs no extra pass over memory.
+//   * LDS images hold 1 byte per element: weights 36.9 KB + halo (10 x 34 pixels, 8x32 tiles) 21.8 KB -> TWO 4-wave blocks per CU,
+//     so one block's staging / epilogue runs under the other's MFMAs (the bf16 image of the same tile shape does not fit twice).
+//   * a lane's 16-byte chunk = 16 consecutive k of its row = the operands of TWO MFMAs (k order inside a 64-wide pair is a free
+//     choice as long as both operands agree).
+// HBM tensors stay bf16: only the operand precision of the forward MFMAs changes; dgrad / wgrad use the bf16 kernels.
+// ------------------------------------------------------------------------------------------------------------------------
+typedef long i64;
+
+__device__ __forceinline__ i64 pack_fp8x8(const float (&v)[8], float scale) {
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * scale, v[1] * scale, lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * scale, v[3] * scale, lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4] * scale, v[5] * scale, hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6] * scale, v[7] * scale, hi, true);
+    return (i64)(((unsigned long)(unsigned)hi << 32) | (unsigned long)(unsigned)lo);
+}
+
+// max over the block of a non-negative per-thread value (NW waves)
+template <int NW>
+__device__ __forceinline__ float block_max(float v, float* scratch /*[NW]*/) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    __syncthreads();                 // scratch free
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float m = scratch[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) m = fmaxf(m, scratch[w]);
+    return m;
+}
+
+template <bool AFF, bool RELU, int RS, int CIN, int NT, int TH, int TW, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void conv3x3_lds_fp8_kernel(ConvArgs a, int tiles_w, int tiles_h, int tpe, int tpb, int nblk, int bpe) {
+    constexpr int AW = TW + 2, AH = TH + 2;
+    constexpr int K = 9 * CIN;
+    constexpr int KP = K / 64;                  // k pairs: 64 k = two MFMA k-steps per 16-byte chunk
+    constexpr int CH = CIN / 16;                // 16-byte (16 x fp8) chunks per halo pixel
+    constexpr int WCH = K / 16;                 // 16-byte chunks per weight row
+    constexpr int MTW = (TH * TW / 16) / NW;
+    constexpr int MPR = TW / 16;
+    constexpr int NTHR = NW * 64;
+    static_assert(MTW >= 2 && MTW % 2 == 0 && (TH * TW / 16) % NW == 0, "each wave owns an even number of m-tiles");
+    constexpr int W_BYTES = NT * 16 * K;
+    constexpr int HALO_BYTES = AH * AW * CIN;
+    constexpr int EPI_BYTES = NW * EpiLds<NT>::FLOATS * 4;
+    constexpr int H_REGION = HALO_BYTES > EPI_BYTES ? HALO_BYTES : EPI_BYTES;
+    static_assert(NW * STATS_SX_FLOATS * 4 <= H_REGION, "fold scratch reuses the halo region");
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];
+    char* wsm = smem_all;
+    char* hsm = smem_all + W_BYTES;
+    __shared__ float red[NW * NT * 16 * 2];
+    __shared__ float mx[NW];
+    __shared__ __attribute__((aligned(32))) float aff_s[AFF ? 2 * AFF_MAXC : 8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int H = a.H, W = a.W;
+    const int n_base = blockIdx.y * NT * 16;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk / 8, r = nblk % 8, xcd = bid % 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+    }
+    const int event = bid / bpe;
+    const int t0 = event * tpe + (bid - event * bpe) * tpb;
+    const int t1 = min(t0 + tpb, (event + 1) * tpe);
+    if (t0 >= t1) return;
+
+    // ---- weights: bf16 pack -> amax of the block's slice -> e4m3 image in LDS
+    float inv_sw;
+    {
+        constexpr int TOT = NT * 16 * (K / 8), PER = (TOT + NTHR - 1) / NTHR, SB = 6;      // 8-value source chunks
+        // two passes over the (L2-resident) pack instead of holding PER chunks in registers across the block reduction
+        auto wload = [&](int j) -> bf16x8 {
+            const int idx = threadIdx.x + j * NTHR;
+            if (idx >= TOT) return zero8();
+            const int row = idx / (K / 8), kc = idx - row * (K / 8);
+            if (n_base + row >= a.Cout) return zero8();
+            return *(const bf16x8*)((const bf16*)a.w + (long)(n_base + row) * a.Kpad + kc * 8);
+        };
+        float am = 0.f;
+        for (int j0 = 0; j0 < PER; j0 += SB) {
+            bf16x8 wr[SB];
+#pragma unroll
+            for (int j = 0; j < SB; ++j) wr[j] = (j0 + j < PER) ? wload(j0 + j) : zero8();
+#pragma unroll
+            for (int j = 0; j < SB; ++j)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) am = fmaxf(am, fabsf(bf2f(wr[j][i])));
+        }
+        am = block_max<NW>(am, mx);
+        const float sw = 224.f / fmaxf(am, 1e-20f);
+        inv_sw = 1.f / sw;
+        for (int j0 = 0; j0 < PER; j0 += SB) {
+            bf16x8 wr[SB];
+#pragma unroll
+            for (int j = 0; j < SB; ++j) wr[j] = (j0 + j < PER) ? wload(j0 + j) : zero8();
+#pragma unroll
+            for (int j = 0; j < SB; ++j) {
+                const int idx = threadIdx.x + (j0 + j) * NTHR;
+                if (j0 + j >= PER || idx >= TOT) continue;
+                const int row = idx / (K / 8), kc = idx - row * (K / 8);
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = bf2f(wr[j][i]);
+                *(i64*)(wsm + (row * WCH + swz<WCH>(swz_key<WCH>(row), kc >> 1)) * 16 + (kc & 1) * 8) = pack_fp8x8(v, sw);
+            }
+        }
+    }
+    float s1[8], s2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
+    int aff_n = -1;
+    for (int t = t0; t < t1; ++t) {
+        const int n = t / (tiles_w * tiles_h);
+        const int trem = t - n * tiles_w * tiles_h;
+        const int h0 = (trem / tiles_w) * TH, w0 = (trem % tiles_w) * TW;
+        if (AFF && n != aff_n) {
+            __syncthreads();
+            stage_aff(aff_s, a.src, n, CIN);
+            aff_n = n;
+        }
+        __syncthreads();
+        // ---- halo: raw bf16 -> prologue -> amax of the tile -> e4m3 image in LDS
+        float inv_sa;
+        {
+            constexpr int TOT = AH * AW * (CIN / 8), PER = (TOT + NTHR - 1) / NTHR, SB = 6;
+            // two passes over the halo (second one from L1 / L2): nothing is held in registers across the block reduction
+            auto hload = [&](int j, bool& ok) -> bf16x8 {
+                const int idx = threadIdx.x + j * NTHR;
+                ok = false;
+                if (idx >= TOT) return zero8();
+                const int hp = idx / (CIN / 8), cc = idx - hp * (CIN / 8);
+                const int hh = h0 - 1 + hp / AW, ww = w0 - 1 + hp % AW;
+                if (!(hh >= 0 && hh < H && ww >= 0 && ww < W)) return zero8();
+                ok = true;
+                const int sh_ = (RS == 1) ? (hh >> 1) : hh, sw_ = (RS == 1) ? (ww >> 1) : ww;
+                return *(const bf16x8*)((const bf16*)a.src.x + (((long)n * a.src.Hs + sh_) * a.src.Ws + sw_) * a.src.Cx + cc * 8);
+            };
+            auto xf = [&](int j, const bf16x8& raw, bool ok, float (&v)[8]) {
+                const int idx = threadIdx.x + j * NTHR;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = bf2f(raw[i]);
+                if (ok) xform8<AFF, RELU>(v, a.src, n, (idx % (CIN / 8)) * 8, aff_s);
+            };
+            float am = 0.f;
+            for (int j0 = 0; j0 < PER; j0 += SB) {
+                bf16x8 rawb[SB];
+                bool okb[SB];
+#pragma unroll
+                for (int j = 0; j < SB; ++j) rawb[j] = hload(j0 + j, okb[j]);
+#pragma unroll
+                for (int j = 0; j < SB; ++j) {
+                    float v[8];
+                    xf(j0 + j, rawb[j], okb[j], v);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) am = fmaxf(am, fabsf(v[i]));
+                }
+            }
+            am = block_max<NW>(am, mx);
+            const float sa = 224.f / fmaxf(am, 1e-20f);
+            inv_sa = 1.f / sa;
+            for (int j0 = 0; j0 < PER; j0 += SB) {
+                bf16x8 rawb[SB];
+                bool okb[SB];
+#pragma unroll
+                for (int j = 0; j < SB; ++j) rawb[j] = hload(j0 + j, okb[j]);
+#pragma unroll
+                for (int j = 0; j < SB; ++j) {
+                    const int idx = threadIdx.x + (j0 + j) * NTHR;
+                    if (idx >= TOT) continue;
+                    const int hp = idx / (CIN / 8), cc = idx - hp * (CIN / 8);
+                    float v[8];
+                    xf(j0 + j, rawb[j], okb[j], v);
+                    *(i64*)(hsm + (hp * CH + swz<CH>(swz_key<CH>(hp % AW), cc >> 1)) * 16 + (cc & 1) * 8) = pack_fp8x8(v, sa);
+                }
+            }
+        }
+        __syncthreads();
+        f32x4 acc[MTW][NT];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // fragment addresses: per-lane swizzled chunk offset + immediates (see the bf16 kernel)
+        constexpr int NVA = (CH >= 4) ? CH / 4 : 1;           // swizzle variants of the A chunk index (CIN / 64)
+        constexpr int NVB = (WCH % 16 == 4) ? 1 : ((WCH % 16 == 8) ? 2 : 4);
+        int offA[MTW][3][NVA];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+            const int mt = wave * MTW + m;
+            const int col = (mt % MPR) * 16 + lr;
+            const int base = ((mt / MPR) * AW + col) * CH * 16;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                for (int v = 0; v < NVA; ++v) offA[m][dx][v] = base + swz<CH>(swz_key<CH>(col + dx), v * 4 + lg) * 16;
+        }
+        int offB[NVB];
+#pragma unroll
+        for (int v = 0; v < NVB; ++v) offB[v] = lr * WCH * 16 + swz<WCH>(swz_key<WCH>(lr), v * 4 + lg) * 16;
+        struct F2 { i64 lo, hi; };
+        auto lda = [&](int kp, F2(&x)[MTW]) {
+            const int tap = (kp * 64) / CIN, cq = ((kp * 64) % CIN) / 64;
+            const int imm = ((tap / 3) * AW + (tap % 3)) * CH * 16;
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) x[m] = *(const F2*)(hsm + offA[m][tap % 3][cq] + imm);
+        };
+        auto ldb = [&](int kp, F2(&b)[NT]) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b[nt] = *(const F2*)(wsm + offB[kp % NVB] + nt * 16 * WCH * 16 + (kp / NVB) * NVB * 64);
+        };
+        F2 aq[2][MTW], bq[2][NT];
+        lda(0, aq[0]);
+        ldb(0, bq[0]);
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp) {
+            if (kp + 1 < KP) {
+                lda(kp + 1, aq[(kp + 1) & 1]);
+                ldb(kp + 1, bq[(kp + 1) & 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(aq[kp & 1][m].lo, bq[kp & 1][nt].lo, acc[m][nt], 0, 0, 0);
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(aq[kp & 1][m].hi, bq[kp & 1][nt].hi, acc[m][nt], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const float inv = inv_sw * inv_sa;
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[m][nt][r] *= inv;
+        __syncthreads();
+        float* epi = (float*)hsm + wave * EpiLds<NT>::FLOATS;
+#pragma unroll
+        for (int half = 0; half < MTW / 2; ++half) {
+            const int mt = wave * MTW + 2 * half;
+            auto pix = [&](int row, long& m, int& nn, int& h, int& w) -> bool {
+                const int mtt = mt + (row >> 4);
+                nn = n;
+                h = h0 + mtt / MPR;
+                w = w0 + (mtt % MPR) * 16 + (row & 15);
+                m = ((long)n * H + h) * W + w;
+                return h < H && w < W;
+            };
+            const f32x4(&sub)[2][NT] = *reinterpret_cast<const f32x4(*)[2][NT]>(&acc[2 * half]);
+            conv_epilogue<false, NT>(a, sub, epi, n_base, pix, s1, s2);
+        }
+    }
+    if (a.stats != nullptr) {
+        __syncthreads();
+        stats_flush<NT, NW>(a, s1, s2, n_base, red, (float*)hsm, bid, event);
+    }
+}
+
+template <bool AFF, bool RELU, int RS>
+static int lds_fp8_launch(const ConvArgs& a, hipStream_t st) {
+    const int n_events = (a.stats != nullptr && a.n_per_event > 0) ? a.N / a.n_per_event : 1;
+#define F8_LAUNCH(CINV, NTV, THV, TWV, NWV)                                                                                        \
+    {                                                                                                                              \
+        const int tiles_w = (a.W + TWV - 1) / TWV, tiles_h = (a.H + THV - 1) / THV;                                                \
+        const int ntiles = a.N * tiles_w * tiles_h;                                                                                \
+        const int tpe = ntiles / n_events;                                                                                         \
+        const int gy = (a.Cout + 16 * NTV - 1) / (16 * NTV);                                                                       \
+        int tpb = (ntiles * gy + 1023) / 1024;          /* two resident blocks per CU */                                           \
+        if (tpb < 1) tpb = 1;                                                                                                      \
+        if (tpb > tpe) tpb = tpe;                                                                                                  \
+        const int bpe = (tpe + tpb - 1) / tpb;                                                                                     \
+        const int nblk = bpe * n_events;                                                                                           \
+        const size_t halo = (size_t)(THV + 2) * (TWV + 2) * CINV, epi = (size_t)NWV * EpiLds<NTV>::FLOATS * 4;                     \
+        const size_t lds = (size_t)NTV * 16 * 9 * CINV + (halo > epi ? halo : epi);                                                \
+        hipLaunchKernelGGL((conv3x3_lds_fp8_kernel<AFF, RELU, RS, CINV, NTV, THV, TWV, NWV>), dim3(nblk, gy), dim3(NWV * 64), lds, \
+                           st, a, tiles_w, tiles_h, tpe, tpb, nblk, bpe);                                                          \
+        return 1;                                                                                                                  \
+    }
+    if (a.Cin == 64 && a.Cout % 64 == 0 && a.H >= 8 && a.W >= 32) F8_LAUNCH(64, 4, 8, 32, 4)
+    if (a.Cin == 128 && a.Cout % 32 == 0 && a.H >= 8 && a.W >= 16) F8_LAUNCH(128, 2, 8, 16, 4)
+#undef F8_LAUNCH
+    return 0;
+}
+
 // 1 = launched, 0 = not applicable (caller falls back to conv3x3_halo), < 0 = error
 int conv3x3_lds_launch(const ConvArgs& a, hipStream_t st) {
     if (a.taps != 9 || (a.src.rs != 0 && a.src.rs != 1) || a.Kpad != 9 * a.Cin || (a.Cin != 64 && a.Cin != 128)) return 0;
     if (a.src.scale != nullptr && a.Cin > AFF_MAXC) return 0;
     const bool aff = a.src.scale != nullptr, relu = a.src.relu != 0;
+    if ((a.flags & IEAGAN_CONV_FP8) && a.bnb_scale == nullptr && a.mask == nullptr) {      // forward launches only
+        int r = 0;
+        if (a.src.rs == 0) r = aff ? (relu ? lds_fp8_launch<true, true, 0>(a, st) : lds_fp8_launch<true, false, 0>(a, st))
+                                   : (relu ? lds_fp8_launch<false, true, 0>(a, st) : lds_fp8_launch<false, false, 0>(a, st));
+        else r = aff ? (relu ? lds_fp8_launch<true, true, 1>(a, st) : lds_fp8_launch<true, false, 1>(a, st))
+                     : (relu ? lds_fp8_launch<false, true, 1>(a, st) : lds_fp8_launch<false, false, 1>(a, st));
+        if (r != 0) return r;
+    }
     if (a.src.rs == 0) {
         if (aff && relu) return lds_launch<true, true, 0, false>(a, st);
         if (aff) return lds_launch<true, false, 0, false>(a, st);

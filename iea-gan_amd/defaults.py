@@ -46,5 +46,6 @@ def default_config() -> dict:
              load_optim=True)
     # -- keys that exist only here (defaults = reference behaviour)
     c.update(hip_graph=False)            # replay the train step from captured HIP graphs (one graph; three in data-parallel runs)
+    c.update(conv_dtype="bf16")          # 'fp8': e4m3 MFMA operands in the forward of the C >= 64 3x3 layers (BASELINE configs[4])
     c.update(events_per_step=1)          # E events of batch_size images per GPU and step (BASELINE configs[3])
     return c

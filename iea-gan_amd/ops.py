@@ -514,6 +514,7 @@ def _conv_launch(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu, N, Hc, Wc, Cin,
 
 
 USE_TR_READ = True        # ds_read_b64_tr_b16 operand reads in conv_wgrad (False: scalar LDS reads)
+FP8_FORWARD = False       # forward MFMA operands of the C = 64 / 128 3x3 layers in OCP e4m3 (config conv_dtype='fp8', BASELINE configs[4])
 TWO_STAGE_WGRAD = False   # conv_wgrad: partial slabs + reduction launch instead of float atomics when the atomic volume is large
 FUSE_BN_BACKWARD = True   # BatchNorm-apply backward inside the dgrad epilogue (False: the stand-alone prologue_bwd pass)
 
@@ -575,9 +576,10 @@ class ConvFn(torch.autograd.Function):
         out = torch.empty(N, Hc, Wc, Cout, dtype=BF16, device=x.device)
         stats = new_stats(Cout, x.device, events) if want_stats else None
         nstride = 0 if (scale is None or scale.dim() == 1) else scale.shape[1]
+        flags = H.CONV_FP8 if (FP8_FORWARD and taps == 9 and Cin in (64, 128)) else 0
         _conv_launch(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu, N, Hc, Wc, Cin, Cout, taps, rec.kpad, rec.w_fwd,
                      bias, ra, ra.shape[-1] if ra is not None else 0, Ca, ra_rs, rb,
-                     rb.shape[-1] if rb is not None else 0, None, out, stats, npe=N // events)
+                     rb.shape[-1] if rb is not None else 0, None, out, stats, npe=N // events, flags=flags)
         ctx.events = events
         ctx.rec, ctx.cfg = rec, (taps, rs, relu, Ca, ra_rs, nstride, Hc, Wc)
         ctx.ra_shape = ra.shape if ra is not None else None

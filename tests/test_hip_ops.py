@@ -231,6 +231,42 @@ def test_streaming_1x1_agrees_with_gather(dev, Cin, Cout, Hh, Ww, N, aff, relu, 
         assert not torch.allclose(outs[0][1][0], outs[0][1][1])          # the events really are separate accumulators
 
 
+@pytest.mark.parametrize("N,Hh,Ww,C,aff", [(8, 64, 192, 64, False), (6, 32, 96, 64, True), (5, 20, 40, 64, False), (4, 16, 48, 128, True),
+                                            (3, 8, 24, 128, False)])
+def test_fp8_forward_conv_vs_bf16_and_fp32(dev, N, Hh, Ww, C, aff):
+    """BASELINE configs[4]: the C = 64 / 128 3x3 forward launches with OCP e4m3 MFMA operands (per-slice weight scale, per-tile
+    activation scale, fp32 accumulate).  Stated tolerance: relative L2 error of the output <= 4e-2 against fp32 (e4m3 carries 3
+    mantissa bits: ~3 % per product; measured 3.5e-2), vs <= 6e-3 for the bf16 operands (measured 1.7e-3); statistics <= 5e-2."""
+    import _hip, ops
+    torch.manual_seed(31)
+    x = torch.randn(N, Hh, Ww, C, device=dev).to(BF)
+    kpad = ops._kpad(9 * C)
+    wf = torch.randn(C, C, 3, 3, device=dev) / math.sqrt(9 * C)
+    w = wf.permute(0, 2, 3, 1).reshape(C, 9 * C).to(BF).contiguous()
+    bias = 0.1 * torch.randn(C, device=dev)
+    sc = (1 + 0.3 * torch.randn(N, C, device=dev)) if aff else None
+    sh = (0.2 * torch.randn(N, C, device=dev)) if aff else None
+    a = x.float().permute(0, 3, 1, 2)
+    if aff:
+        a = a * sc[:, :, None, None] + sh[:, :, None, None]
+    a = F.relu(a)
+    ref = F.conv2d(a, w.float().view(C, 3, 3, C).permute(0, 3, 1, 2), bias, 1, 1)
+    outs = {}
+    for name, flags in (("bf16", 0), ("fp8", _hip.CONV_FP8)):
+        out = torch.empty(N, Hh, Ww, C, device=dev, dtype=BF)
+        st = ops.new_stats(C, dev)
+        ops._conv_launch(x, C, Hh, Ww, 0, sc, sh, C if aff else 0, True, N, Hh, Ww, C, C, 9, kpad, w, bias, None, 0, 0, 0, None, 0, None, out, st,
+                         flags=flags)
+        outs[name] = (nchw(out), st.sum((0, 1)))
+    rel = lambda t: float((t - ref).norm() / ref.norm())
+    e16, e8 = rel(outs["bf16"][0]), rel(outs["fp8"][0])
+    print(f"rel-L2 vs fp32: bf16 {e16:.2e}, fp8 {e8:.2e}")
+    assert e16 <= 6e-3 and e8 <= 4e-2, (e16, e8)
+    assert e8 > e16                                        # the fp8 path really ran with fp8 operands
+    close(outs["fp8"][1][0], ref.sum((0, 2, 3)), 5e-2, "fp8 stat sum")
+    close(outs["fp8"][1][1], (ref * ref).sum((0, 2, 3)), 5e-2, "fp8 stat sumsq")
+
+
 def conv_reference(x, W, u, bias, scale, shift, relu, rs, taps, ra, ra_mode, Ca, rb):
     """fp32 NCHW composite with the kernel's rounding points (A operand and weights in bf16)."""
     a = x
