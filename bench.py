@@ -266,7 +266,7 @@ def kernel_report(res, m, args):
                                          achieved=mf[0]["flops"] / (mf[0]["ms"] * 1e-3) / 1e12,
                                          frac=mf[0]["flops"] / (mf[0]["ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS)
     fams = []
-    for r in recs[:(60 if args.shape_tags else 14)]:
+    for r in recs[:(400 if args.shape_tags else 14)]:
         sec = r["ms"] * 1e-3
         bmin = r.get("bytes_min") or r["bytes"]
         fams.append({"name": r["name"], "launches_per_step": r["launches"] / prof_steps, "ms_per_step": r["ms"] / prof_steps,

@@ -315,6 +315,7 @@ static void launch_wgrad_pro(const WgradArgs& a, hipStream_t st, int mt, dim3 gr
 // Second stage of the two-stage accumulation: dw[row][k] += sum over the S pixel-split slabs, k < K.  grid (K/4 float4 columns in
 // blocks of 256, rows, slab chunks of RED_CHUNK): consecutive threads read consecutive float4 of one slab row.
 #define RED_CHUNK 32
+#define WG_TWO_STAGE_MIN_BYTES (8L << 20)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, int chunk, int Cout, int Kpad, int K) {
     const int c4 = blockIdx.x * 256 + threadIdx.x;
     const int row = blockIdx.y;
@@ -380,7 +381,6 @@ static int wgrad_plan(const WgradArgs& a, int use_tr, WgradPlan& p) {
     const bool two_stage = a.partials != nullptr;
     long blocks_goal = dw_elems <= 4096 ? 2048 : dw_elems <= 12288 ? 1024 : (dw_elems <= 65536 || tiles > 128) ? 512 : 256;
     if (p.special && a.Cin <= 64) blocks_goal = a.Cin == 16 ? 1024 : (a.Cin == 32 ? 512 : 256);
-    if (two_stage) blocks_goal = 512;
     long target = blocks_goal / (p.gy * p.gz);
     if (target < 64) target = 64;
     int tpb = (int)((tiles + target - 1) / target);
@@ -396,12 +396,8 @@ static int wgrad_plan(const WgradArgs& a, int use_tr, WgradPlan& p) {
     // workspace worth using: the slabs of the split count a two-stage launch would take, when the atomic volume of the direct
     // form is large (>= 2 MB of adds) -- small dW x few splits stays with the direct atomics (one launch less)
     {
-        long t2 = 512 / (p.gy * p.gz);
-        if (t2 < 64) t2 = 64;
-        const int tpb2 = (int)((tiles + t2 - 1) / t2) < 1 ? 1 : (int)((tiles + t2 - 1) / t2);
-        const long gx2 = (tiles + tpb2 - 1) / tpb2;
         const long direct_bytes = (long)p.gx * dw_elems * 4;
-        p.ws_elems = (!two_stage && direct_bytes >= (2L << 20) && gx2 > 1) ? gx2 * (long)a.Cout * a.Kpad : (two_stage ? (long)p.gx * a.Cout * a.Kpad : 0);
+        p.ws_elems = (two_stage || (direct_bytes >= WG_TWO_STAGE_MIN_BYTES && p.gx > 1)) ? (long)p.gx * a.Cout * a.Kpad : 0;
     }
     return 0;
 }

@@ -111,6 +111,7 @@ class SNPass:
 
     def __init__(self, bank, ctx):
         self.bank, self.ctx, self.arena, self._ok = bank, ctx, None, None
+        self.side = None             # side stream carrying this pass's weight-gradient launches (joined in flush)
 
     def usable(self) -> bool:
         if not DIRECT_GRADS or self.bank.owner is None or self.bank.bwd is None:
@@ -139,6 +140,9 @@ class SNPass:
     def flush(self):
         if self.arena is None:
             return
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
+            self.side = None
         b = self.bank
         H.call("ieagan_sn_backward_batched", b.bwd["table"].data_ptr(), b.bwd["work"].data_ptr(), b.bwd["nwork"], b.arena.data_ptr(),
                self.ctx.data_ptr(), self.arena.data_ptr(), b.owner.grad.data_ptr(), H.stream())
@@ -515,7 +519,19 @@ def _conv_launch(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu, N, Hc, Wc, Cin,
 
 USE_TR_READ = True        # ds_read_b64_tr_b16 operand reads in conv_wgrad (False: scalar LDS reads)
 FP8_FORWARD = False       # forward MFMA operands of the C = 64 / 128 3x3 layers in OCP e4m3 (config conv_dtype='fp8', BASELINE configs[4])
-TWO_STAGE_WGRAD = False   # conv_wgrad: partial slabs + reduction launch instead of float atomics when the atomic volume is large
+TWO_STAGE_WGRAD = True    # conv_wgrad: partial slabs + reduction launch instead of float atomics when the atomic volume is large
+# Weight-gradient launches of a training backward pass go to a side stream: nothing in the pass reads dW before the batched
+# spectral-norm backward at its end (SNPass.flush joins), so they run under the dgrad chain of this and the following layers --
+# the mid / small feature maps (<= 240 blocks on 256 CUs, long float-atomic tails) leave most of the chip idle on their own.
+WGRAD_SIDE_STREAM = True
+_WGRAD_STREAMS = {}
+
+
+def wgrad_stream(device) -> "torch.cuda.Stream":
+    key = torch.device(device).index or 0
+    if key not in _WGRAD_STREAMS:
+        _WGRAD_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _WGRAD_STREAMS[key]
 FUSE_BN_BACKWARD = True   # BatchNorm-apply backward inside the dgrad epilogue (False: the stand-alone prologue_bwd pass)
 
 
@@ -646,6 +662,13 @@ class ConvFn(torch.autograd.Function):
                        H.stream())
         if has_rb and need[6]:
             d_rb = g[..., Ca:]
+        # ---- weight-gradient accumulator; fork point of the side stream (g and the zeroed accumulators are ready here)
+        dwp = fork = None
+        if need[1]:
+            dwp = sn_scratch(rec, "w", (Cout, rec.kpad), dev)
+            if (WGRAD_SIDE_STREAM and rec.deferred and d_ra is not g and d_rb is None):
+                fork = torch.cuda.Event()
+                fork.record(torch.cuda.current_stream())
         # ---- data gradient
         dx = dscale = dshift = None
         if need[0] or (has_aff and (need[3] or need[4])):
@@ -705,17 +728,30 @@ class ConvFn(torch.autograd.Function):
         # ---- weight gradient (skipped entirely when the parameter is frozen, e.g. D in the G phase)
         dW = None
         if need[1]:
-            dwp = sn_scratch(rec, "w", (Cout, rec.kpad), dev)
             d = H.WgradDesc(N, Hc, Wc, Cin, Cout, taps, rec.kpad,
                             H.src_desc(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu), g.data_ptr(), Cg, dwp.data_ptr(), 0, 0, None,
                             H.ptr(colsum) if colsum_in_wgrad else None)
-            # large weight x many pixel splits: the blocks store partial slabs and a second launch folds them (two-stage
-            # accumulation; the float-atomic tail was the longest phase of these launches)
-            ws_n = H.lib().ieagan_conv_wgrad_workspace(d, int(USE_TR_READ)) if TWO_STAGE_WGRAD else 0
-            if ws_n > 0:
-                ws = torch.empty(ws_n, dtype=torch.float32, device=dev)
-                d.partials = ws.data_ptr()
-            H.call("ieagan_conv_wgrad", d, int(USE_TR_READ), H.stream())
+
+            def launch():
+                # large weight x many pixel splits: the blocks store partial slabs and a second launch folds them (two-stage
+                # accumulation; the float-atomic tail was the longest phase of these launches)
+                ws_n = H.lib().ieagan_conv_wgrad_workspace(d, int(USE_TR_READ)) if TWO_STAGE_WGRAD else 0
+                if ws_n > 0:
+                    ws = torch.empty(ws_n, dtype=torch.float32, device=dev)
+                    d.partials = ws.data_ptr()
+                H.call("ieagan_conv_wgrad", d, int(USE_TR_READ), H.stream())
+
+            if fork is not None:
+                side = wgrad_stream(dev)
+                with torch.cuda.stream(side):
+                    side.wait_event(fork)
+                    launch()
+                for t in (x, g, scale, shift):          # read by the side stream after this node has returned them to the pool
+                    if t is not None:
+                        t.record_stream(side)
+                rec.pass_.side = side
+            else:
+                launch()
             dW, dbias = sn_backward(dwp, weight, rec, colsum if (has_bias and need[2]) else None, ctx.bias_ref)
         elif has_bias and need[2]:
             dbias = colsum.sum(0)
