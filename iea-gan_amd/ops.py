@@ -37,7 +37,9 @@ class _ZeroPool:
         self.buf, self.pos = {}, {}
 
     def take(self, n: int, device) -> torch.Tensor:
-        key = str(device)
+        # one chunk per (device, stream): a chunk is filled on the stream that is current when it is created, and only that
+        # stream may carve it without further synchronisation
+        key = (str(device), torch.cuda.current_stream(device).cuda_stream)
         n_al = (n + 63) // 64 * 64
         if n_al > self.CHUNK // 4:
             return torch.zeros(n, dtype=torch.float32, device=device)
@@ -112,6 +114,7 @@ class SNPass:
     def __init__(self, bank, ctx):
         self.bank, self.ctx, self.arena, self._ok = bank, ctx, None, None
         self.side = None             # side stream carrying this pass's weight-gradient launches (joined in flush)
+        self.stream = torch.cuda.current_stream(ctx.device)      # the stream this pass runs on (autograd runs its backward there too)
 
     def usable(self) -> bool:
         if not DIRECT_GRADS or self.bank.owner is None or self.bank.bwd is None:
@@ -140,8 +143,11 @@ class SNPass:
     def flush(self):
         if self.arena is None:
             return
+        cur = torch.cuda.current_stream()
+        if self.stream != cur:
+            cur.wait_stream(self.stream)
         if self.side is not None:
-            torch.cuda.current_stream().wait_stream(self.side)
+            cur.wait_stream(self.side)
             self.side = None
         b = self.bank
         H.call("ieagan_sn_backward_batched", b.bwd["table"].data_ptr(), b.bwd["work"].data_ptr(), b.bwd["nwork"], b.arena.data_ptr(),
@@ -528,10 +534,13 @@ _WGRAD_STREAMS = {}
 
 
 def wgrad_stream(device) -> "torch.cuda.Stream":
-    key = torch.device(device).index or 0
+    """Side stream for the weight-gradient launches issued from the current stream."""
+    key = (torch.device(device).index or 0, torch.cuda.current_stream(device).cuda_stream)
     if key not in _WGRAD_STREAMS:
         _WGRAD_STREAMS[key] = torch.cuda.Stream(device=device)
     return _WGRAD_STREAMS[key]
+
+
 FUSE_BN_BACKWARD = True   # BatchNorm-apply backward inside the dgrad epilogue (False: the stand-alone prologue_bwd pass)
 
 

@@ -1,0 +1,12 @@
+"""bench.py with module flags of ``ops`` overridden (development aid): EXP=TWO_LANES=False,WGRAD_SIDE_STREAM=False python tools/exp_bench.py ..."""
+import os, sys
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(root, "iea-gan_amd"), root]
+import ops
+for kv in os.environ.get("EXP", "").split(","):
+    if kv:
+        k, v = kv.split("=")
+        assert hasattr(ops, k), k
+        setattr(ops, k, eval(v))
+import bench
+bench.main()
