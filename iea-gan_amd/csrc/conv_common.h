@@ -98,9 +98,30 @@ struct EpiLds {
 
 // BNBOK: the BatchNorm-backward epilogue mode (ieagan_conv_desc.bnb_*) is compiled in -- a separate instantiation of the
 // plain-prologue kernels (a dgrad launch has no prologue), so that every other variant keeps its register budget.
+// This lane's 8 bias values in the epilogue (channel chunk lane % (2*NT) of the block's n-tile group): requested at kernel start --
+// as eight scalar loads inside the epilogue they were a global-memory round trip per tile in every consumer wave.
+template <int NT>
+__device__ __forceinline__ void load_bias8(const ConvArgs& a, int n_base, float (&bv)[8]) {
+    const int co0 = n_base + ((threadIdx.x & 63) % (NT * 2)) * 8;
+    f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias != nullptr && co0 < a.Cout) {          // Cout % 8 == 0 and the bias vector is 32-byte aligned (launcher)
+        lo = *(const f32x4*)(a.bias + co0);
+        hi = *(const f32x4*)(a.bias + co0 + 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        bv[i] = lo[i];
+        bv[4 + i] = hi[i];
+    }
+}
+
 template <bool BNBOK, int NT, int MTS = 2, typename PixFn>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x4 (&acc)[MTS][NT], float* wlds, int n_base, PixFn pix,
-                                              float (&s1)[8], float (&s2)[8]) {
+                                              float (&s1)[8], float (&s2)[8], const float* bias_pre = nullptr,
+                                              const bf16x8* mask_pre = nullptr) {
+    // bias_pre: this lane's 8 bias values (channel chunk lane % CPP), loaded once by a kernel that walks several tiles;
+    // mask_pre: the ReLU-mask / BatchNorm-input chunks of this call's (16*MTS*CPP)/64 iterations, requested by the caller ahead of
+    // time (same lane -> (row, chunk) mapping as below) so that their latency is not paid inside the epilogue.
     constexpr int LDW = EpiLds<NT>::LDW;
     constexpr int CPP = NT * 2;                         // 8-channel chunks per pixel
     static_assert((16 * MTS * CPP) % 64 == 0, "epilogue rows x chunks must fill whole waves");
@@ -122,7 +143,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x4 (&a
     const bool bnb = BNBOK && a.bnb_scale != nullptr;
     float bv[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) bv[i] = (a.bias && ch_ok) ? a.bias[co0 + i] : 0.f;
+    for (int i = 0; i < 8; ++i) bv[i] = bias_pre ? bias_pre[i] : ((a.bias && ch_ok) ? a.bias[co0 + i] : 0.f);
     const int H = a.H, W = a.W;
 #pragma unroll
     for (int it = 0; it < (16 * MTS * CPP) / 64; ++it) {
@@ -135,7 +156,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x4 (&a
         if (!ok) continue;
         float v[8] = {lo[0] + bv[0], lo[1] + bv[1], lo[2] + bv[2], lo[3] + bv[3], hi[0] + bv[4], hi[1] + bv[5], hi[2] + bv[6], hi[3] + bv[7]};
         if (bnb) {                      // v = d(conv input); the conv input was relu(x*scale + shift): fold that apply's backward
-            const bf16x8 xv = *(const bf16x8*)((const bf16*)a.mask + m * a.Cout + co0);
+            const bf16x8 xv = mask_pre ? mask_pre[it] : *(const bf16x8*)((const bf16*)a.mask + m * a.Cout + co0);
             const long so = (long)n * a.bnb_nstride + co0;
             const f32x4 sc0 = *(const f32x4*)(a.bnb_scale + so), sc1 = *(const f32x4*)(a.bnb_scale + so + 4);
             const f32x4 sh0 = *(const f32x4*)(a.bnb_shift + so), sh1 = *(const f32x4*)(a.bnb_shift + so + 4);
@@ -149,7 +170,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x4 (&a
                 v[i] = d * sc;
             }
         } else if (a.mask != nullptr) {        // fused ReLU backward of the main path (residual is added after it)
-            const bf16x8 mk = *(const bf16x8*)((const bf16*)a.mask + m * a.Cout + co0);
+            const bf16x8 mk = mask_pre ? mask_pre[it] : *(const bf16x8*)((const bf16*)a.mask + m * a.Cout + co0);
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = (bf2f(mk[i]) > 0.f) ? v[i] : 0.f;
         }

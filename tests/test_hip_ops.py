@@ -158,10 +158,14 @@ def test_halo_and_gather_kernels_agree(dev):
                                        (4, 16, 48, 128),       # C = 128: conv3x3_lds (4 waves, 8x16 tiles)
                                        (3, 8, 24, 128),        # C = 128 on the 8x24 map (ragged columns)
                                        (8, 128, 96, 32),       # C = 32: prefetching variant, unrolled K loop
-                                       (4, 100, 70, 16)])      # C = 16: prefetching variant, ragged tiles
+                                       (4, 100, 70, 16),       # C = 16: prefetching variant, ragged tiles
+                                       (12, 100, 200, 16),     # C = 16, >= 1024 tiles: conv3x3_ws (producer / consumer waves), ragged tiles
+                                       (2, 256, 768, 16)])     # C = 16 at the production map: conv3x3_ws, 3 tiles per persistent block
 def test_specialised_halo_variants_agree_with_gather(dev, N, Hh, Ww, C):
     """Every channel-specialised 3x3 kernel (compile-time K loop, software pipeline, LDS weights, register prefetch of the
-    next tile) against the plain gather kernel on the same operands, with a ReLU prologue, a ReLU-mask epilogue and statistics."""
+    next tile, producer / consumer waves) against the plain gather kernel on the same operands: ReLU prologue + ReLU-mask
+    epilogue + statistics together, and the two combinations the train step issues (forward: ReLU prologue, statistics;
+    dgrad: plain prologue, ReLU mask) -- conv3x3_ws only takes those."""
     import _hip, ops
     torch.manual_seed(9)
     x = torch.randn(N, Hh, Ww, C, device=dev).to(BF)
@@ -171,17 +175,47 @@ def test_specialised_halo_variants_agree_with_gather(dev, N, Hh, Ww, C):
     w = w.to(BF)
     bias = 0.1 * torch.randn(C, device=dev)
     mask = torch.randn(N, Hh, Ww, C, device=dev).to(BF)
-    outs = []
-    for force in (0, _hip.CONV_FORCE_GATHER, _hip.CONV_NO_LDS_WEIGHTS):      # conv3x3_lds (C = 64 / 128) | conv_gather | conv3x3_halo
-        out = torch.empty(N, Hh, Ww, C, device=dev, dtype=BF)
-        st = ops.new_stats(C, dev)
-        ops._conv_launch(x, C, Hh, Ww, 0, None, None, 0, True, N, Hh, Ww, C, C, 9, kpad, w, bias, None, 0, 0, 0, None, 0, mask, out, st,
-                         flags=force)
-        outs.append((out, st.sum((0, 1))))
-    close(outs[0][0], outs[1][0], 4e-3, "lds / halo vs gather out")
-    close(outs[0][1], outs[1][1], 2e-3, "lds / halo vs gather stats")
-    close(outs[2][0], outs[1][0], 4e-3, "halo vs gather out")
-    close(outs[2][1], outs[1][1], 2e-3, "halo vs gather stats")
+    for relu, mk in ((True, mask), (True, None), (False, mask)):
+        outs = []
+        for force in (0, _hip.CONV_FORCE_GATHER, _hip.CONV_NO_LDS_WEIGHTS):      # conv3x3_lds / conv3x3_ws | conv_gather | conv3x3_halo
+            out = torch.empty(N, Hh, Ww, C, device=dev, dtype=BF)
+            st = ops.new_stats(C, dev)
+            ops._conv_launch(x, C, Hh, Ww, 0, None, None, 0, relu, N, Hh, Ww, C, C, 9, kpad, w, bias, None, 0, 0, 0, None, 0, mk, out, st,
+                             flags=force)
+            outs.append((out, st.sum((0, 1))))
+        tag = f"relu={relu} mask={mk is not None}: "
+        close(outs[0][0], outs[1][0], 4e-3, tag + "lds / ws / halo vs gather out")
+        close(outs[0][1], outs[1][1], 2e-3, tag + "lds / ws / halo vs gather stats")
+        close(outs[2][0], outs[1][0], 4e-3, tag + "halo vs gather out")
+        close(outs[2][1], outs[1][1], 2e-3, tag + "halo vs gather stats")
+
+
+def test_ws_kernel_affine_prologue_and_event_statistics(dev):
+    """conv3x3_ws with the ccbn prologue (per-image scale / shift staged per producer wave), an upsampled source and per-event
+    statistics, against conv3x3_halo on the same operands (the halo kernel itself is checked against fp32 PyTorch below)."""
+    import _hip, ops
+    torch.manual_seed(10)
+    C, N, E = 16, 8, 2
+    for rs, (Hs, Ws) in ((0, (128, 384)), (1, (64, 192))):
+        Hh, Ww = (Hs, Ws) if rs == 0 else (2 * Hs, 2 * Ws)
+        x = torch.randn(N, Hs, Ws, C, device=dev).to(BF)
+        kpad = ops._kpad(9 * C)
+        w = torch.zeros(C, kpad, device=dev)
+        w[:, :9 * C] = torch.randn(C, 9 * C, device=dev) / math.sqrt(9 * C)
+        w = w.to(BF)
+        bias = 0.1 * torch.randn(C, device=dev)
+        sc = 1 + 0.2 * torch.randn(N, C, device=dev)
+        sh = 0.2 * torch.randn(N, C, device=dev)
+        res = []
+        for force in (0, _hip.CONV_NO_LDS_WEIGHTS):
+            out = torch.empty(N, Hh, Ww, C, device=dev, dtype=BF)
+            st = ops.new_stats(C, dev, E)
+            ops._conv_launch(x, C, Hs, Ws, rs, sc, sh, C, True, N, Hh, Ww, C, C, 9, kpad, w, bias, None, 0, 0, 0, None, 0, None, out, st,
+                             npe=N // E, flags=force)
+            res.append((out, st.sum(1)))
+        close(res[0][0], res[1][0], 4e-3, f"rs={rs}: ws vs halo out")
+        close(res[0][1], res[1][1], 2e-3, f"rs={rs}: ws vs halo per-event stats")
+        assert (res[0][1][0] - res[0][1][1]).abs().max() > 0       # the two events really have different statistics
 
 
 @pytest.mark.parametrize("Cin,Cout,Hh,Ww,N,aff,relu,res,mask,events", [
@@ -480,6 +514,7 @@ def test_bn_finalize_matches_batch_norm(dev):
 
 
 @pytest.mark.parametrize("taps,C,Cout,Hh,Ww,N,res", [(9, 16, 16, 64, 96, 3, None),        # halo dgrad kernel (C = 16 variant)
+                                                     (9, 16, 16, 128, 384, 6, None),      # conv3x3_ws dgrad kernel (>= 1024 tiles)
                                                      (9, 64, 64, 16, 48, 3, None),        # halo dgrad kernel (C = 64)
                                                      (1, 64, 16, 32, 64, 3, None),        # gather dgrad kernel
                                                      (1, 32, 64, 128, 384, 3, "same"),    # streaming dgrad kernel + shortcut gradient
