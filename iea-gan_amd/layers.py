@@ -165,9 +165,11 @@ class Attention(nn.Module):
         """xa: bf16 [N,H,W,C].  theta/phi/g/o 1x1 convs and the streaming-softmax affinity are HIP kernels;
         the 2x2 max-pool of phi / g and the final gamma*o + x are two small HIP element-wise kernels."""
         N, Hh, Ww, C = xa.shape
-        theta, _ = self.theta.fused(xa, recs[prefix + ".theta"])
-        phi, _ = self.phi.fused(xa, recs[prefix + ".phi"])
-        g, _ = self.g.fused(xa, recs[prefix + ".g"])
+        # xa feeds theta, phi, g and the residual: their four gradients are summed inside the dgrad kernels (ops.SumLink)
+        link = ops.SumLink(4) if (torch.is_grad_enabled() and xa.requires_grad and ops.FUSE_SHORTCUT_GRAD) else None
+        theta, _ = self.theta.fused(xa, recs[prefix + ".theta"], res_in=link)
+        phi, _ = self.phi.fused(xa, recs[prefix + ".phi"], res_in=link)
+        g, _ = self.g.fused(xa, recs[prefix + ".g"], res_in=link)
 
         phi, g = ops.MaxPool2Fn.apply(phi), ops.MaxPool2Fn.apply(g)
         q = theta.view(N, Hh * Ww, C // 8)
@@ -175,7 +177,7 @@ class Attention(nn.Module):
         v = g.view(N, Hh * Ww // 4, C // 2)
         o_pre = ops.NLAttentionFn.apply(q, k, v).view(N, Hh, Ww, C // 2)
         o, _ = self.o.fused(o_pre, recs[prefix + ".o"])
-        return ops.GammaResidualFn.apply(o, xa, self.gamma)
+        return ops.GammaResidualFn.apply(o, xa, self.gamma, link)
 
     def forward(self, x, y=None):
         H.require_gpu()

@@ -152,6 +152,9 @@ class SNPass:
         b = self.bank
         H.call("ieagan_sn_backward_batched", b.bwd["table"].data_ptr(), b.bwd["work"].data_ptr(), b.bwd["nwork"], b.arena.data_ptr(),
                self.ctx.data_ptr(), self.arena.data_ptr(), b.owner.grad.data_ptr(), H.stream())
+        if cur != self.stream:                   # launched from another stream than the one whose pool owns these buffers
+            self.arena.record_stream(cur)
+            self.ctx.record_stream(cur)
         self.arena = None
 
 
@@ -579,6 +582,27 @@ class ResLink:
         return out
 
 
+class SumLink(ResLink):
+    """Fan-in of the gradients of one activation that feeds ``expected`` fused consumers (non-local block: theta, phi, g and
+    the residual all read the block input).  Each consumer's backward adds the running sum inside the kernel that produces its own
+    contribution and deposits the result; the last one to arrive hands the total to autograd, the others return None --
+    instead of ``expected`` full-size tensors and ``expected - 1`` library add kernels."""
+    __slots__ = ("expected", "seen")
+
+    def __init__(self, expected):
+        super().__init__()
+        self.expected, self.seen = expected, 0
+
+    def arrive(self, g, C):
+        """Register this consumer's (already accumulated) gradient ``g``; returns the total if it is the last one, else None."""
+        self.seen += 1
+        if self.seen == self.expected:
+            self.g, self.ready, self.seen = None, False, 0
+            return g
+        self.deposit(g, C, C, 0)
+        return None
+
+
 _PLACEHOLDERS = {}
 
 
@@ -685,8 +709,9 @@ class ConvFn(torch.autograd.Function):
             fuse_mask = relu and not has_aff and rs == 0
             plain = not relu and not has_aff
             lg = lC = lCa = lmode = None
+            fan_in = res_in if isinstance(res_in, SumLink) else None
             if res_in is not None and not res_in.ready:
-                res_in = None          # the shortcut operand needed no gradient (e.g. a detached block input)
+                res_in = None          # the shortcut operand needed no gradient (e.g. a detached block input) / first of a fan-in
             if res_in is not None:
                 lg, lC, lCa, lmode = res_in.take()
             bn_link = getattr(scale, "_bn_link", None) if has_aff else None
@@ -734,6 +759,10 @@ class ConvFn(torch.autograd.Function):
                     H.call("ieagan_prologue_bwd", da.data_ptr(), x.data_ptr(), Cx, H.ptr(scale), H.ptr(shift), nstride, int(relu),
                            rs, dx.data_ptr(), H.ptr(dscale), H.ptr(dshift), N, Hs, Ws, Cin, H.ptr(lg), lC or 0, lCa or 0, rmode,
                            H.stream())
+            if fan_in is not None:
+                if not (plain and rs == 0 and dx is da):
+                    raise RuntimeError("a fan-in gradient link needs a plain same-resolution conv")
+                dx = fan_in.arrive(dx, Cin)
         # ---- weight gradient (skipped entirely when the parameter is frozen, e.g. D in the G phase)
         dW = None
         if need[1]:
@@ -1078,11 +1107,12 @@ class GammaResidualFn(torch.autograd.Function):
     """out = gamma * o + x on bf16 maps with the learnable scalar read from device memory (layers.py:300)."""
 
     @staticmethod
-    def forward(ctx, o, x, gamma):
+    def forward(ctx, o, x, gamma, link=None):
         o, x = o.contiguous(), x.contiguous()
         out = torch.empty_like(x)
         H.call("ieagan_gamma_residual_fwd", o.data_ptr(), x.data_ptr(), gamma.data_ptr(), out.data_ptr(), x.numel(), H.stream())
         ctx.save_for_backward(o, gamma)
+        ctx.link = link
         return out
 
     @staticmethod
@@ -1093,7 +1123,12 @@ class GammaResidualFn(torch.autograd.Function):
         part = zeros((STAT_REPL,), o.device)
         H.call("ieagan_gamma_residual_bwd", d.data_ptr(), o.data_ptr(), gamma.data_ptr(), d_o.data_ptr(), part.data_ptr(), o.numel(),
                H.stream())
-        return d_o, d, part.sum().reshape(gamma.shape)
+        d_x = d
+        if ctx.link is not None:      # fan-in of the block input's gradients (SumLink): the residual path's share is d itself
+            if ctx.link.ready:        # (normally this node runs first and only deposits)
+                d_x = d + ctx.link.take()[0]
+            d_x = ctx.link.arrive(d_x, d.shape[-1])
+        return d_o, d_x, part.sum().reshape(gamma.shape), None
 
 
 # =====================================================================================================

@@ -1,11 +1,11 @@
-"""Where do the device-to-device copies of one eager train step come from?  (development aid)"""
-import os, sys, collections
+"""Which aten::copy_ / contiguous / clone calls does one eager train step still issue, and from where?  (development aid)"""
+import os, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(root, "iea-gan_amd"), root]
 import torch
 from torch.profiler import profile, ProfilerActivity
 import bench
-import model, train_fns, utils
+import model, train_fns, utils, ops
 
 cfg = bench.bench_config()
 cfg["hip_graph"] = False
@@ -22,11 +22,10 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
     train(x, y)
     torch.cuda.synchronize()
-cnt = collections.Counter()
-for e in prof.events():
-    if e.name in ("aten::copy_", "aten::clone", "aten::contiguous", "aten::_to_copy") and e.device_time_total >= 0:
-        st = [s for s in (e.stack or []) if "iea-gan_amd" in s or "bench.py" in s]
-        key = (e.name, str(e.input_shapes)[:60], st[0][-70:] if st else "?")
-        cnt[key] += 1
-for k, v in cnt.most_common(40):
-    print(v, k)
+rows = []
+for e in prof.key_averages(group_by_input_shape=True, group_by_stack_n=8):
+    if e.key in ("aten::copy_", "aten::clone", "aten::contiguous", "aten::fill_", "aten::zero_", "aten::add_", "aten::cat"):
+        rows.append((e.count, e.key, str(e.input_shapes)[:90], [s for s in e.stack if "iea-gan_amd" in s or "tests" in s][:3]))
+rows.sort(key=lambda r: -r[0])
+for c, k, s, stck in rows[:60]:
+    print(f"{c:5d} {k:18s} {s}\n        {stck}")
