@@ -13,7 +13,7 @@ from collections import defaultdict
 def family(name):
     n = re.sub(r"^void ", "", name)
     if n.startswith("conv_gather_kernel<1") or n.startswith("conv1x1_stream_kernel"): return "conv1x1_gather"      # (bench.py family names)
-    if n.startswith("conv3x3_lds_kernel"): return "conv3x3_halo"
+    if n.startswith("conv3x3_lds_kernel") or n.startswith("conv3x3_ws_kernel"): return "conv3x3_halo"
     if n.startswith("wgrad_reduce_kernel"): return "conv3x3_wgrad"
     if n.startswith("conv_gather_kernel<9"): return "conv3x3_gather"
     if n.startswith("conv3x3_halo_kernel"): return "conv3x3_halo"
