@@ -79,8 +79,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_lds_kernel(ConvArgs a
             *(bf16x8*)(wsm + (row * WCH + swz<WCH>(swz_key<WCH>(row), kc)) * 16) = v;
         }
     }
-    float s1[8], s2[8], bias_r[8];
-    load_bias8<NT>(a, n_base, bias_r);
+    float s1[8], s2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
     int aff_n = -1;
@@ -203,7 +202,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_lds_kernel(ConvArgs a
                 return h < H && w < W;
             };
             const f32x4(&sub)[2][NT] = *reinterpret_cast<const f32x4(*)[2][NT]>(&acc[2 * half]);
-            conv_epilogue<BNB, NT>(a, sub, epi, n_base, pix, s1, s2, bias_r);
+            conv_epilogue<BNB, NT>(a, sub, epi, n_base, pix, s1, s2);
         }
     }
     if (a.stats != nullptr) {
@@ -359,8 +358,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_lds_fp8_kernel(ConvArgs a,
             }
         }
     }
-    float s1[8], s2[8], bias_r[8];
-    load_bias8<NT>(a, n_base, bias_r);
+    float s1[8], s2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
     int aff_n = -1;
@@ -503,7 +501,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_lds_fp8_kernel(ConvArgs a,
                 return h < H && w < W;
             };
             const f32x4(&sub)[2][NT] = *reinterpret_cast<const f32x4(*)[2][NT]>(&acc[2 * half]);
-            conv_epilogue<false, NT>(a, sub, epi, n_base, pix, s1, s2, bias_r);
+            conv_epilogue<false, NT>(a, sub, epi, n_base, pix, s1, s2);
         }
     }
     if (a.stats != nullptr) {

@@ -65,8 +65,8 @@ __global__ __launch_bounds__(256, 4) void conv_gather_kernel(ConvArgs a) {
     const int ksteps = a.Kpad >> 5;
     const bool col_ok = (n_base + (NT - 1) * 16 + lr) < a.Cout;     // only NT == 1 can have a half-empty n-tile
     const bf16* wrow = (const bf16*)a.w + (long)(col_ok ? n_base + lr : 0) * a.Kpad + lg * 8;
-    float bias_r[8];
-    load_bias8<NT>(a, n_base, bias_r);              // in flight during the K loop
+    // (the bias stays a load inside the epilogue here: requested before the K loop it costs 8-12 VGPRs over the whole kernel and
+    //  one to two resident waves per SIMD on most variants -- one tile per block, the other blocks hide that latency)
     for (int ks = 0; ks < ksteps; ++ks) {
         const int k = ks * 32 + lg * 8;
         int tap = 0, c = k;
@@ -113,10 +113,10 @@ __global__ __launch_bounds__(256, 4) void conv_gather_kernel(ConvArgs a) {
         for (int half = 0; half < 2; ++half) {
             auto pixh = [&](int row, long& m, int& n, int& h, int& w) -> bool { return pix(row + 16 * half, m, n, h, w); };
             const f32x4(&sub)[1][NT] = *reinterpret_cast<const f32x4(*)[1][NT]>(&acc[half]);
-            conv_epilogue<BNB, NT, 1>(a, sub, epi + wave * EROWS * EpiLds<NT>::LDW, n_base, pixh, s1, s2, bias_r);
+            conv_epilogue<BNB, NT, 1>(a, sub, epi + wave * EROWS * EpiLds<NT>::LDW, n_base, pixh, s1, s2);
         }
     } else {
-        conv_epilogue<BNB, NT>(a, acc, epi + wave * EROWS * EpiLds<NT>::LDW, n_base, pix, s1, s2, bias_r);
+        conv_epilogue<BNB, NT>(a, acc, epi + wave * EROWS * EpiLds<NT>::LDW, n_base, pix, s1, s2);
     }
     static_assert(4 * EROWS * EpiLds<NT>::LDW >= 4 * STATS_SX_FLOATS, "epilogue buffer doubles as the statistics scratch");
     if (a.stats != nullptr) {
@@ -266,10 +266,9 @@ __global__ __launch_bounds__(256, ((CIN >= 64 && PF == 0) ? 2 : (CIN == 16 ? 4 :
         }
     };
 
-    float s1[8], s2[8], bias_r[8];
+    float s1[8], s2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
-    load_bias8<NT>(a, n_base, bias_r);
     int pbase[4];   // byte offset of this lane's pixel in m-tile mt at tap (0,0): row 2*wave + (mt>>1), col (mt&1)*16 + lr
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) pbase[mt] = ((2 * wave + (mt >> 1)) * AW + (mt & 1) * 16 + lr) * PS;
@@ -432,7 +431,7 @@ __global__ __launch_bounds__(256, ((CIN >= 64 && PF == 0) ? 2 : (CIN == 16 ? 4 :
                 return h < H && w < W;
             };
             const f32x4(&sub)[2][NT] = *reinterpret_cast<const f32x4(*)[2][NT]>(&acc[2 * half]);
-            conv_epilogue<BNB, NT>(a, sub, epi, n_base, pix, s1, s2, bias_r);
+            conv_epilogue<BNB, NT>(a, sub, epi, n_base, pix, s1, s2);
         }
         __syncthreads();      // every wave has left its epilogue buffer: the region is the next tile's halo / the fold scratch
     }
