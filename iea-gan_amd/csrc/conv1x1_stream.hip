@@ -113,8 +113,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs a, int 
                 const long m = wbase + ep * (MTS * 16) + (it * 64 + lane) / CPP;
                 const bool ok = m < M && ch_ok;
                 if (has_mask && ok) pm[ep][it] = *(const bf16x8*)((const bf16*)a.mask + m * a.Cout + co0);
+                // (else-if: two conditional loads into the same registers made the second one wait for every outstanding load)
                 if (res_ptr != nullptr && ok) pr[ep][it] = *(const bf16x8*)(res_ptr + m * res_stride);
-                if (ra_up && ok) {          // shortcut at half resolution (nearest x2): pixel (n, h, w) reads (n, h/2, w/2)
+                else if (ra_up && ok) {     // shortcut at half resolution (nearest x2): pixel (n, h, w) reads (n, h/2, w/2)
                     const int rem = (int)(m - (long)n_img * HW);
                     const int h = rem / W, w = rem - h * W;
                     pr[ep][it] = *(const bf16x8*)((const bf16*)a.ra + (((long)n_img * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1)) * a.Cra + co0);

@@ -19,8 +19,11 @@ __device__ __forceinline__ void xform8(float (&v)[8], const SrcDesc& s, int n, i
     if (AFF) {
         f32x8 sc, sh;
         if (aff != nullptr) {
-            sc = *(const f32x8*)(aff + c);
-            sh = *(const f32x8*)(aff + AFF_MAXC + c);
+            // `aff` is an LDS table: read it through an LDS-qualified pointer.  As a generic pointer these were FLAT loads, which
+            // count on the vector-memory counter as well -- every use then waited for ALL outstanding global prefetches.
+            typedef const __attribute__((address_space(3))) f32x8* lds_f32x8;
+            sc = *(lds_f32x8)(aff + c);
+            sh = *(lds_f32x8)(aff + AFF_MAXC + c);
         } else {
             sc = *(const f32x8*)(s.scale + (long)n * s.aff_nstride + c);
             sh = *(const f32x8*)(s.shift + (long)n * s.aff_nstride + c);
