@@ -202,7 +202,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_lds_kernel(ConvArgs a
                 return h < H && w < W;
             };
             const f32x4(&sub)[2][NT] = *reinterpret_cast<const f32x4(*)[2][NT]>(&acc[2 * half]);
-            conv_epilogue<BNB, NT>(a, sub, epi, n_base, pix, s1, s2);
+            conv_epilogue<BNB, NT, 2, false>(a, sub, epi, n_base, pix, s1, s2);
         }
     }
     if (a.stats != nullptr) {
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_lds_fp8_kernel(ConvArgs a,
                 return h < H && w < W;
             };
             const f32x4(&sub)[2][NT] = *reinterpret_cast<const f32x4(*)[2][NT]>(&acc[2 * half]);
-            conv_epilogue<false, NT>(a, sub, epi, n_base, pix, s1, s2);
+            conv_epilogue<false, NT, 2, false>(a, sub, epi, n_base, pix, s1, s2);
         }
     }
     if (a.stats != nullptr) {

@@ -118,7 +118,7 @@ __device__ __forceinline__ void load_bias8(const ConvArgs& a, int n_base, float 
     }
 }
 
-template <bool BNBOK, int NT, int MTS = 2, typename PixFn>
+template <bool BNBOK, int NT, int MTS = 2, bool EARLY = true, typename PixFn>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x4 (&acc)[MTS][NT], float* wlds, int n_base, PixFn pix,
                                               float (&s1)[8], float (&s2)[8], const float* bias_pre = nullptr,
                                               const bf16x8* mask_pre = nullptr) {
@@ -144,22 +144,58 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x4 (&a
     const int co0 = n_base + cc * 8;
     const bool ch_ok = co0 < a.Cout;
     const bool bnb = BNBOK && a.bnb_scale != nullptr;
+    const int H = a.H, W = a.W;
+    constexpr int EIT = (16 * MTS * CPP) / 64;
+    // ---- phase 1: every global operand of this call is requested before anything is computed -- bias (two 16-byte loads),
+    // ReLU mask / BatchNorm input, same- or half-resolution residual chunk.  In program order "load, use, load, use" each of
+    // them was a memory round trip of its own inside the epilogue (the latency-bound small-map launches felt it most).
+    f32x4 b_lo = {0.f, 0.f, 0.f, 0.f}, b_hi = {0.f, 0.f, 0.f, 0.f};
+    if (bias_pre == nullptr && a.bias != nullptr && ch_ok) {        // Cout % 8 == 0; the bias vector is 16-byte aligned (launcher)
+        b_lo = *(const f32x4*)(a.bias + co0);
+        b_hi = *(const f32x4*)(a.bias + co0 + 4);
+    }
+    // EARLY = false (the 3x3 kernels, whose register budget is spent on accumulators and prefetched halos): the mask / residual
+    // chunks are loaded where they are used, as before
+    const bool want_mask = EARLY && a.mask != nullptr && mask_pre == nullptr;
+    const bool ra_here = a.ra != nullptr && co0 < a.Ca;
+    const bool rb_here = !ra_here && a.rb != nullptr && co0 >= a.Ca;
+    bf16x8 mk_r[EIT], rs_r[EIT];
+    long m_r[EIT];
+    bool ok_r[EIT];
+#pragma unroll
+    for (int it = 0; it < EIT; ++it) {
+        const int row = (it * 64 + lane) / CPP;
+        int n, h, w;
+        ok_r[it] = pix(row, m_r[it], n, h, w) && ch_ok;
+        mk_r[it] = zero8();
+        rs_r[it] = zero8();
+        if (!ok_r[it]) continue;
+        const long m = m_r[it];
+        if (want_mask) mk_r[it] = *(const bf16x8*)((const bf16*)a.mask + m * a.Cout + co0);
+        if (!EARLY) continue;
+        if (ra_here && a.ra_rs == 0) rs_r[it] = *(const bf16x8*)((const bf16*)a.ra + m * a.Cra + co0);
+        else if (ra_here && a.ra_rs == 1)      // operand lives at half resolution: nearest x2 upsample
+            rs_r[it] = *(const bf16x8*)((const bf16*)a.ra + (((long)n * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1)) * a.Cra + co0);
+        else if (rb_here) rs_r[it] = *(const bf16x8*)((const bf16*)a.rb + m * a.Crb + (co0 - a.Ca));
+    }
     float bv[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) bv[i] = bias_pre ? bias_pre[i] : ((a.bias && ch_ok) ? a.bias[co0 + i] : 0.f);
-    const int H = a.H, W = a.W;
+    for (int i = 0; i < 8; ++i) bv[i] = bias_pre ? bias_pre[i] : (i < 4 ? b_lo[i & 3] : b_hi[i & 3]);
+    // ---- phase 2
 #pragma unroll
-    for (int it = 0; it < (16 * MTS * CPP) / 64; ++it) {
+    for (int it = 0; it < EIT; ++it) {
         const int row = (it * 64 + lane) / CPP;
-        long m;
-        int n, h, w;
-        const bool ok = pix(row, m, n, h, w) && ch_ok;
+        const long m = m_r[it];
+        const bool ok = ok_r[it];
         const f32x4 lo = *(const f32x4*)(wlds + row * LDW + cc * 8);
         const f32x4 hi = *(const f32x4*)(wlds + row * LDW + cc * 8 + 4);
         if (!ok) continue;
         float v[8] = {lo[0] + bv[0], lo[1] + bv[1], lo[2] + bv[2], lo[3] + bv[3], hi[0] + bv[4], hi[1] + bv[5], hi[2] + bv[6], hi[3] + bv[7]};
         if (bnb) {                      // v = d(conv input); the conv input was relu(x*scale + shift): fold that apply's backward
-            const bf16x8 xv = mask_pre ? mask_pre[it] : *(const bf16x8*)((const bf16*)a.mask + m * a.Cout + co0);
+            const bf16x8 xv = mask_pre ? mask_pre[it] : (EARLY ? mk_r[it] : *(const bf16x8*)((const bf16*)a.mask + m * a.Cout + co0));
+            int n, h, w;
+            long mm;
+            pix(row, mm, n, h, w);
             const long so = (long)n * a.bnb_nstride + co0;
             const f32x4 sc0 = *(const f32x4*)(a.bnb_scale + so), sc1 = *(const f32x4*)(a.bnb_scale + so + 4);
             const f32x4 sh0 = *(const f32x4*)(a.bnb_shift + so), sh1 = *(const f32x4*)(a.bnb_shift + so + 4);
@@ -173,23 +209,28 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x4 (&a
                 v[i] = d * sc;
             }
         } else if (a.mask != nullptr) {        // fused ReLU backward of the main path (residual is added after it)
-            const bf16x8 mk = mask_pre ? mask_pre[it] : *(const bf16x8*)((const bf16*)a.mask + m * a.Cout + co0);
+            const bf16x8 mk = mask_pre ? mask_pre[it] : (EARLY ? mk_r[it] : *(const bf16x8*)((const bf16*)a.mask + m * a.Cout + co0));
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = (bf2f(mk[i]) > 0.f) ? v[i] : 0.f;
         }
-        if (a.ra != nullptr && co0 < a.Ca) {
-            const bf16* ra = (const bf16*)a.ra;
+        if (ra_here) {
             float rv[8];
-            if (a.ra_rs == 0) {
-                const bf16x8 t = *(const bf16x8*)(ra + m * a.Cra + co0);
+            if (a.ra_rs != 2) {
+                bf16x8 t = rs_r[it];
+                if (!EARLY) {
+                    int n, h, w;
+                    long mm;
+                    pix(row, mm, n, h, w);
+                    t = (a.ra_rs == 0) ? *(const bf16x8*)((const bf16*)a.ra + m * a.Cra + co0)
+                                       : *(const bf16x8*)((const bf16*)a.ra + (((long)n * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1)) * a.Cra + co0);
+                }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) rv[i] = bf2f(t[i]);
-            } else if (a.ra_rs == 1) {      // operand lives at half resolution: nearest x2 upsample
-                const bf16x8 t = *(const bf16x8*)(ra + (((long)n * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1)) * a.Cra + co0);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) rv[i] = bf2f(t[i]);
-            } else {                        // operand lives at double resolution: 2x2 average
-                const bf16* p = ra + (((long)n * (2 * H) + 2 * h) * (2 * W) + 2 * w) * a.Cra + co0;
+            } else {                        // operand lives at double resolution: 2x2 average (four loads: not requested ahead)
+                int n, h, w;
+                long mm;
+                pix(row, mm, n, h, w);
+                const bf16* p = (const bf16*)a.ra + (((long)n * (2 * H) + 2 * h) * (2 * W) + 2 * w) * a.Cra + co0;
                 const long rs_ = (long)2 * W * a.Cra;
                 const bf16x8 t0 = *(const bf16x8*)p, t1 = *(const bf16x8*)(p + a.Cra), t2 = *(const bf16x8*)(p + rs_),
                              t3 = *(const bf16x8*)(p + rs_ + a.Cra);
@@ -198,8 +239,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const f32x4 (&a
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] += a.ra_scale * rv[i];
-        } else if (a.rb != nullptr && co0 >= a.Ca) {
-            const bf16x8 t = *(const bf16x8*)((const bf16*)a.rb + m * a.Crb + (co0 - a.Ca));
+        } else if (rb_here) {
+            const bf16x8 t = EARLY ? rs_r[it] : *(const bf16x8*)((const bf16*)a.rb + m * a.Crb + (co0 - a.Ca));
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] += bf2f(t[i]);
         }

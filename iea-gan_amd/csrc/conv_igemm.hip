@@ -113,10 +113,10 @@ __global__ __launch_bounds__(256, 4) void conv_gather_kernel(ConvArgs a) {
         for (int half = 0; half < 2; ++half) {
             auto pixh = [&](int row, long& m, int& n, int& h, int& w) -> bool { return pix(row + 16 * half, m, n, h, w); };
             const f32x4(&sub)[1][NT] = *reinterpret_cast<const f32x4(*)[1][NT]>(&acc[half]);
-            conv_epilogue<BNB, NT, 1>(a, sub, epi + wave * EROWS * EpiLds<NT>::LDW, n_base, pixh, s1, s2);
+            conv_epilogue<BNB, NT, 1, (RS != 2)>(a, sub, epi + wave * EROWS * EpiLds<NT>::LDW, n_base, pixh, s1, s2);      // (pooled-source variants: no registers to spare)
         }
     } else {
-        conv_epilogue<BNB, NT>(a, acc, epi + wave * EROWS * EpiLds<NT>::LDW, n_base, pix, s1, s2);
+        conv_epilogue<BNB, NT, 2, (RS != 2)>(a, acc, epi + wave * EROWS * EpiLds<NT>::LDW, n_base, pix, s1, s2);
     }
     static_assert(4 * EROWS * EpiLds<NT>::LDW >= 4 * STATS_SX_FLOATS, "epilogue buffer doubles as the statistics scratch");
     if (a.stats != nullptr) {
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256, ((CIN >= 64 && PF == 0) ? 2 : (CIN == 16 ? 4 :
                 return h < H && w < W;
             };
             const f32x4(&sub)[2][NT] = *reinterpret_cast<const f32x4(*)[2][NT]>(&acc[2 * half]);
-            conv_epilogue<BNB, NT>(a, sub, epi, n_base, pix, s1, s2);
+            conv_epilogue<BNB, NT, 2, false>(a, sub, epi, n_base, pix, s1, s2);
         }
         __syncthreads();      // every wave has left its epilogue buffer: the region is the next tile's halo / the fold scratch
     }

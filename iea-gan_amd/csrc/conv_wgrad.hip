@@ -188,7 +188,10 @@ __global__ __launch_bounds__(256, (CINV > 0 ? (CINV == 16 ? 4 : (CINV == 32 ? 3 
         __syncthreads();
         if (PFW && tile + 1 < tile_end) request(tile + 1);        // in flight during the MFMAs below
         if (do_colsum) {      // bias gradient: column sums of the staged g tile (thread = column t % GC, pixel phase t / GC)
-            for (int px = threadIdx.x / GC; px < WG_TH * WG_TW; px += 256 / GC) csum += bf2f(lds_g[px * GS + (threadIdx.x % GC)]);
+            // (unrolled: as a rolled loop every one of the GC/2 reads was an LDS round trip of its own -- longer than the MFMA loop)
+            const bf16* colp = lds_g + (threadIdx.x / GC) * GS + (threadIdx.x % GC);
+#pragma unroll 8
+            for (int i = 0; i < GC / 2; ++i) csum += bf2f(colp[i * (256 / GC) * GS]);
         }
         // ---- 4 k-steps of 32 pixels (two tile rows each) x NJ n-tiles, as ONE software pipeline over the 4*NJ (k-step, n-tile)
         // pairs: the B fragment of pair s+2 (and, at the start of a k-step, the A fragments of the NEXT k-step) is requested
@@ -255,9 +258,11 @@ __global__ __launch_bounds__(256, (CINV > 0 ? (CINV == 16 ? 4 : (CINV == 32 ? 3 
         if (ntg < nt_total) {
             if (a.partials != nullptr) {          // two-stage accumulation: this pixel split's slab, plain coalesced stores
                 float* slab = a.partials + (long)blockIdx.x * a.Cout * a.Kpad;
+#pragma unroll 4
                 for (int row = wave; row < GC; row += 4)
                     if (cout0 + row < a.Cout) slab[(long)(cout0 + row) * a.Kpad + kcol] = T[row * 64 + lane];
             } else {
+#pragma unroll 4
                 for (int row = wave; row < GC; row += 4)
                     if (cout0 + row < a.Cout) atomicAdd(a.dw + (long)(cout0 + row) * a.Kpad + kcol, T[row * 64 + lane]);
             }
