@@ -92,7 +92,35 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs a, int 
             }
         }
     };
+    // Software pipeline of depth one over the pixel groups: at the top of iteration g EVERY operand of group g (A fragments, ReLU
+    // mask, residual chunks) is already in registers -- requested during iteration g-1 -- and one explicit wait retires them;
+    // then everything of group g+1 is requested and group g is computed without touching the vector-memory counter again.
+    // (Requesting this group's epilogue operands and the next group's A fragments at the same point, as before, made the
+    // compiler drain the counter -- vmcnt(0) -- in front of the first MFMA: the loads sit under per-lane conditions, so it cannot
+    // count how many younger loads may stay in flight.)
+    bf16x8 pm[EP][ITER], pr[EP][ITER], pm_n[EP][ITER], pr_n[EP][ITER];   // pr: same-resolution residual operand (A or B, by chunk)
+    auto load_epi = [&](int g, bf16x8(&m_)[EP][ITER], bf16x8(&r_)[EP][ITER]) {
+        const long gb = (long)g * GP;
+        const int n_im = (int)(gb / HW);
+        const long wb = gb + wave * (MT * 16);
+#pragma unroll
+        for (int ep = 0; ep < EP; ++ep)
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const long m = wb + ep * (MTS * 16) + (it * 64 + lane) / CPP;
+                const bool ok = m < M && ch_ok;
+                if (has_mask && ok) m_[ep][it] = *(const bf16x8*)((const bf16*)a.mask + m * a.Cout + co0);
+                // (else-if: two conditional loads into the same registers made the second one wait for every outstanding load)
+                if (res_ptr != nullptr && ok) r_[ep][it] = *(const bf16x8*)(res_ptr + m * res_stride);
+                else if (ra_up && ok) {     // shortcut at half resolution (nearest x2): pixel (n, h, w) reads (n, h/2, w/2)
+                    const int rem = (int)(m - (long)n_im * HW);
+                    const int h = rem / W, w = rem - h * W;
+                    r_[ep][it] = *(const bf16x8*)((const bf16*)a.ra + (((long)n_im * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1)) * a.Cra + co0);
+                }
+            }
+    };
     load_A(g0, cur);
+    load_epi(g0, pm, pr);
     int aff_n = -1;
     for (int g = g0; g < g1; ++g) {
         const long gbase = (long)g * GP;
@@ -104,24 +132,11 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs a, int 
             __syncthreads();
         }
         const long wbase = gbase + wave * (MT * 16);
-        // ---- requests first: epilogue operands of THIS group, then the A fragments of the NEXT group
-        bf16x8 pm[EP][ITER], pr[EP][ITER];        // pr: the lane's same-resolution residual operand (A or B, by its channel chunk)
-#pragma unroll
-        for (int ep = 0; ep < EP; ++ep)
-#pragma unroll
-            for (int it = 0; it < ITER; ++it) {
-                const long m = wbase + ep * (MTS * 16) + (it * 64 + lane) / CPP;
-                const bool ok = m < M && ch_ok;
-                if (has_mask && ok) pm[ep][it] = *(const bf16x8*)((const bf16*)a.mask + m * a.Cout + co0);
-                // (else-if: two conditional loads into the same registers made the second one wait for every outstanding load)
-                if (res_ptr != nullptr && ok) pr[ep][it] = *(const bf16x8*)(res_ptr + m * res_stride);
-                else if (ra_up && ok) {     // shortcut at half resolution (nearest x2): pixel (n, h, w) reads (n, h/2, w/2)
-                    const int rem = (int)(m - (long)n_img * HW);
-                    const int h = rem / W, w = rem - h * W;
-                    pr[ep][it] = *(const bf16x8*)((const bf16*)a.ra + (((long)n_img * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1)) * a.Cra + co0);
-                }
-            }
-        if (g + 1 < g1) load_A(g + 1, nxt);
+        __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): group g's operands (requested one iteration ago) have landed
+        if (g + 1 < g1) {
+            load_A(g + 1, nxt);
+            load_epi(g + 1, pm_n, pr_n);
+        }
         // ---- compute + epilogue, one pass of MTS m-tiles at a time (K is tiny: the accumulators of a pass die right away)
 #pragma unroll
         for (int ep = 0; ep < EP; ++ep) {
@@ -216,6 +231,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs a, int 
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) cur[mt][ks] = nxt[mt][ks];
+#pragma unroll
+        for (int ep = 0; ep < EP; ++ep)
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                pm[ep][it] = pm_n[ep][it];
+                pr[ep][it] = pr_n[ep][it];
+            }
     }
     if (a.stats != nullptr) {
         __syncthreads();          // every wave has left its transpose buffer: it now serves as the fold scratch
