@@ -15,8 +15,8 @@
 #define WS_H 8
 #define WS_W 32
 
-template <bool AFF, bool RELU, int RS, int CIN, bool BNB, bool MPF>
-__global__ __launch_bounds__(512, (CIN == 16 ? 4 : 2)) void conv3x3_ws_kernel(ConvArgs a, int tiles_w, int tiles_h, int tpe, int tpb, int nblk, int bpe) {
+template <bool AFF, bool RELU, int RS, int CIN, bool BNB, bool MPF, int NCW>
+__global__ __launch_bounds__((NCW + 4) * 64, (NCW == 4 ? 4 : 3)) void conv3x3_ws_kernel(ConvArgs a, int tiles_w, int tiles_h, int tpe, int tpb, int nblk, int bpe) {
     constexpr int NT = CIN / 16;
     constexpr int AW = WS_W + 2, AH = WS_H + 2;
     constexpr int PS = CIN * 2 + 16;                         // bytes per halo pixel (16 consecutive pixels -> 16 distinct 16-byte slots)
@@ -27,14 +27,15 @@ __global__ __launch_bounds__(512, (CIN == 16 ? 4 : 2)) void conv3x3_ws_kernel(Co
     constexpr int PF = (TOT + 255) / 256;                    // chunks per producer thread and tile (3 / 6)
     constexpr int HALO_BYTES = AH * AW * PS;
     extern __shared__ __attribute__((aligned(16))) char smem_all[];
-    __shared__ float red[4 * NT * 16 * 2];
+    constexpr int RPW = WS_H / NCW, MTW = 2 * RPW;          // tile rows / m-tiles per consumer wave
+    __shared__ float red[NCW * NT * 16 * 2];
     __shared__ __attribute__((aligned(32))) float aff_all[4 * 64];                        // per producer wave: [0, 32) scale, [32, 64) shift of the current image
     char* wlds = smem_all;                                   // [NT*16][WSB]
     char* halo0 = smem_all + NT * 16 * WSB;                  // two halo buffers
-    float* epi_all = (float*)(halo0 + 2 * HALO_BYTES);       // 4 consumer waves x EpiLds<NT>::FLOATS (later: the statistics fold scratch)
+    float* epi_all = (float*)(halo0 + 2 * HALO_BYTES);       // NCW consumer waves x EpiLds<NT>::FLOATS (later: the statistics fold scratch)
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool consumer = wave < 4;
+    const bool consumer = wave < NCW;
     const int lr = lane & 15, lg = lane >> 4;
     const int H = a.H, W = a.W;
     int bid = blockIdx.x;
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(512, (CIN == 16 ? 4 : 2)) void conv3x3_ws_kernel(Co
     const int ntl = t1 - t0;
 
     // weights -> LDS once per block (all 8 waves)
-    for (int idx = threadIdx.x; idx < NT * 16 * (KP / 8); idx += 512) {
+    for (int idx = threadIdx.x; idx < NT * 16 * (KP / 8); idx += (NCW + 4) * 64) {
         const int row = idx / (KP / 8), kc = idx - row * (KP / 8);
         *(bf16x8*)(wlds + row * WSB + kc * 16) = *(const bf16x8*)((const bf16*)a.w + (long)row * KP + kc * 8);
     }
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(512, (CIN == 16 ? 4 : 2)) void conv3x3_ws_kernel(Co
     // one after the prologue, one per tile, one inside / beside the statistics flush.
     if (!consumer) {
         // -------------------------------------------------------------------------------------- producers
-        const int ptid = threadIdx.x - 256;
+        const int ptid = threadIdx.x - NCW * 64;
         bf16x8 rawA[PF], rawB[PF];
         unsigned okA = 0, okB = 0;
         float* aff_w = aff_all + (wave & 3) * 64;
@@ -148,9 +149,9 @@ __global__ __launch_bounds__(512, (CIN == 16 ? 4 : 2)) void conv3x3_ws_kernel(Co
     float s1[8], s2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
-    int pbase[4];   // byte offset of this lane's pixel in m-tile mt at tap (0,0): row 2*wave + (mt>>1), col (mt&1)*16 + lr
+    int pbase[MTW];   // byte offset of this lane's pixel in m-tile mt at tap (0,0): row RPW*wave + (mt>>1), col (mt&1)*16 + lr
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) pbase[mt] = ((2 * wave + (mt >> 1)) * AW + (mt & 1) * 16 + lr) * PS;
+    for (int mt = 0; mt < MTW; ++mt) pbase[mt] = ((RPW * wave + (mt >> 1)) * AW + (mt & 1) * 16 + lr) * PS;
     float* epi = epi_all + wave * EpiLds<NT>::FLOATS;
     // per-lane epilogue constants: the lane owns channel chunk lane % CPP of pixel row (it*64 + lane) / CPP of each half tile
     constexpr int CPP = NT * 2, EIT = (32 * CPP) / 64;
@@ -159,15 +160,15 @@ __global__ __launch_bounds__(512, (CIN == 16 ? 4 : 2)) void conv3x3_ws_kernel(Co
     load_bias8<NT>(a, 0, bias_r);
     // ReLU mask / BatchNorm input of the epilogue: the chunks of tile r+1 are requested before the epilogue of tile r
     constexpr bool has_mask = MPF;                  // launcher: MPF == (a.mask != nullptr)
-    bf16x8 mk_cur[2 * EIT], mk_nxt[2 * EIT];
-    auto mask_request = [&](int t, bf16x8(&mk)[2 * EIT]) {
+    bf16x8 mk_cur[RPW * EIT], mk_nxt[RPW * EIT];
+    auto mask_request = [&](int t, bf16x8(&mk)[RPW * EIT]) {
         int n, h0, w0;
         tile_coords(t, n, h0, w0);
 #pragma unroll
-        for (int half = 0; half < 2; ++half)
+        for (int half = 0; half < RPW; ++half)
 #pragma unroll
             for (int it = 0; it < EIT; ++it) {
-                const int hh = h0 + 2 * wave + half, ww = w0 + (it * 64 + lane) / CPP;
+                const int hh = h0 + RPW * wave + half, ww = w0 + (it * 64 + lane) / CPP;
                 mk[half * EIT + it] = zero8();
                 if (hh < H && ww < W) mk[half * EIT + it] = *(const bf16x8*)((const bf16*)a.mask + (((long)n * H + hh) * W + ww) * CIN + ecc * 8);
             }
@@ -178,19 +179,19 @@ __global__ __launch_bounds__(512, (CIN == 16 ? 4 : 2)) void conv3x3_ws_kernel(Co
         const char* smem = halo0 + (r & 1) * HALO_BYTES;
         int n, h0, w0;
         tile_coords(t0 + r, n, h0, w0);
-        f32x4 acc[4][NT];
+        f32x4 acc[MTW][NT];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         // one-step-ahead software pipeline over the K steps: fragments of step ks+1 requested before the MFMAs of step ks
         constexpr int KS = KP / 32;
-        bf16x8 bq[CIN >= 32 ? 2 : 1][NT], aq[CIN >= 32 ? 2 : 1][4];
+        bf16x8 bq[CIN >= 32 ? 2 : 1][NT], aq[CIN >= 32 ? 2 : 1][MTW];
         auto ldb = [&](int ks, bf16x8(&b)[NT]) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) b[nt] = *(const bf16x8*)(wlds + (nt * 16 + lr) * WSB + (ks * 32 + lg * 8) * 2);
         };
-        auto lda = [&](int ks, bf16x8(&x)[4]) {
+        auto lda = [&](int ks, bf16x8(&x)[MTW]) {
             const int k = ks * 32 + lg * 8;               // lane-group dependent when CIN == 16 (two taps per K step)
             int tap = k / CIN;
             const int c = k - tap * CIN;
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(512, (CIN == 16 ? 4 : 2)) void conv3x3_ws_kernel(Co
             if (!kval) tap = 0;
             const int toff = ((tap / 3) * AW + (tap - (tap / 3) * 3)) * PS + c * 2;
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
+            for (int mt = 0; mt < MTW; ++mt) {
                 x[mt] = *(const bf16x8*)(smem + pbase[mt] + toff);
                 if (!kval) x[mt] = zero8();
             }
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(512, (CIN == 16 ? 4 : 2)) void conv3x3_ws_kernel(Co
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[ks & 1][mt], bq[ks & 1][nt], acc[mt][nt], 0, 0, 0);
@@ -226,15 +227,15 @@ __global__ __launch_bounds__(512, (CIN == 16 ? 4 : 2)) void conv3x3_ws_kernel(Co
                 ldb(ks, bq[0]);
                 lda(ks, aq[0]);
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[0][mt], bq[0][nt], acc[mt][nt], 0, 0, 0);
             }
         }
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {             // tile row 2*wave + half: 32 pixels
-            const int hh = h0 + 2 * wave + half;
+        for (int half = 0; half < RPW; ++half) {           // tile row RPW*wave + half: 32 pixels
+            const int hh = h0 + RPW * wave + half;
             auto pix = [&](int row, long& m, int& nn, int& h, int& w) -> bool {
                 nn = n;
                 h = hh;
@@ -249,11 +250,11 @@ __global__ __launch_bounds__(512, (CIN == 16 ? 4 : 2)) void conv3x3_ws_kernel(Co
         }
         if (has_mask) {
 #pragma unroll
-            for (int i = 0; i < 2 * EIT; ++i) mk_cur[i] = mk_nxt[i];
+            for (int i = 0; i < RPW * EIT; ++i) mk_cur[i] = mk_nxt[i];
         }
         __syncthreads();
     }
-    if (a.stats != nullptr && ntl > 0) stats_flush<NT>(a, s1, s2, 0, red, epi_all, bid, event);
+    if (a.stats != nullptr && ntl > 0) stats_flush<NT, NCW>(a, s1, s2, 0, red, epi_all, bid, event);
 }
 
 template <bool AFF, bool RELU, int RS, bool BNB, bool MPF>
@@ -262,20 +263,20 @@ static int ws_launch_c(const ConvArgs& a, hipStream_t st) {
     const int ntiles = a.N * tiles_w * tiles_h;
     const int n_events = (a.stats != nullptr && a.n_per_event > 0) ? a.N / a.n_per_event : 1;
     const int tpe = ntiles / n_events;
-    int bpe = 512 / n_events;                     // two persistent blocks per CU
+    int bpe = (a.Cin == 16 ? 512 : 256) / n_events;      // persistent blocks: two (C = 16) / one (C = 32) per CU
     if (bpe < 1) bpe = 1;
     int tpb = (tpe + bpe - 1) / bpe;
     if (tpb < 1) tpb = 1;
     bpe = (tpe + tpb - 1) / tpb;
     const int nblk = bpe * n_events;
-#define WS_GO(CINV)                                                                                                          \
+#define WS_GO(CINV, NCWV)                                                                                                    \
     {                                                                                                                        \
         constexpr int NTV = CINV / 16;                                                                                       \
         constexpr int KPV = ((9 * CINV + 31) / 32) * 32;                                                                     \
-        size_t tail = (size_t)4 * EpiLds<NTV>::FLOATS * 4;                                                                   \
-        if (tail < (size_t)4 * STATS_SX_FLOATS * 4) tail = (size_t)4 * STATS_SX_FLOATS * 4;                                   \
+        size_t tail = (size_t)NCWV * EpiLds<NTV>::FLOATS * 4;                                                                \
+        if (tail < (size_t)NCWV * STATS_SX_FLOATS * 4) tail = (size_t)NCWV * STATS_SX_FLOATS * 4;                             \
         const size_t lds = (size_t)NTV * 16 * (KPV * 2 + 16) + 2 * (size_t)(WS_H + 2) * (WS_W + 2) * (CINV * 2 + 16) + tail;  \
-        auto kern = conv3x3_ws_kernel<AFF, RELU, RS, CINV, BNB, MPF>;                                                             \
+        auto kern = conv3x3_ws_kernel<AFF, RELU, RS, CINV, BNB, MPF, NCWV>;                                                  \
         static bool attr_set = false;                                                                                        \
         if (!attr_set) {                                                                                                     \
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
@@ -284,9 +285,10 @@ static int ws_launch_c(const ConvArgs& a, hipStream_t st) {
             }                                                                                                                \
             attr_set = true;                                                                                                 \
         }                                                                                                                    \
-        hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), lds, st, a, tiles_w, tiles_h, tpe, tpb, nblk, bpe);                  \
+        hipLaunchKernelGGL(kern, dim3(nblk), dim3((NCWV + 4) * 64), lds, st, a, tiles_w, tiles_h, tpe, tpb, nblk, bpe);      \
     }
-    WS_GO(16)
+    // C = 16: 4 consumer + 4 producer waves, two blocks per CU
+    WS_GO(16, 4)
 #undef WS_GO
     return 1;
 }
@@ -306,8 +308,9 @@ static int ws_launch_pro(const ConvArgs& a, hipStream_t st) {
 
 // 1 = launched, 0 = not applicable (the caller falls back to conv3x3_halo)
 int conv3x3_ws_launch(const ConvArgs& a, hipStream_t st) {
-    // C = 32 (one 8-wave block per CU: 92 KB of LDS) measured slower than conv3x3_halo's three 4-wave blocks (94 vs 77 us at
-    // 128x384): only the C = 16 layers come here
+    // C = 32 needs 92-110 KB of LDS, i.e. one block per CU: measured slower than conv3x3_halo's three 4-wave blocks with 4 consumer
+    // waves (94 vs 77 us at 128x384) and with 8 (97 vs 73 us) -- nothing runs while the one block waits at its barrier.  Only the
+    // C = 16 layers come here (the kernel stays generic in CIN / NCW).
     if (a.taps != 9 || a.Cin != a.Cout || a.Cin != 16 || a.src.rs == 2) return 0;
     if (a.Kpad != ((9 * a.Cin + 31) / 32) * 32 || a.src.Cx % 8 != 0) return 0;
     const int tiles = a.N * ((a.W + WS_W - 1) / WS_W) * ((a.H + WS_H - 1) / WS_H);

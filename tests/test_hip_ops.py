@@ -160,7 +160,9 @@ def test_halo_and_gather_kernels_agree(dev):
                                        (8, 128, 96, 32),       # C = 32: prefetching variant, unrolled K loop
                                        (4, 100, 70, 16),       # C = 16: prefetching variant, ragged tiles
                                        (12, 100, 200, 16),     # C = 16, >= 1024 tiles: conv3x3_ws (producer / consumer waves), ragged tiles
-                                       (2, 256, 768, 16)])     # C = 16 at the production map: conv3x3_ws, 3 tiles per persistent block
+                                       (2, 256, 768, 16),      # C = 16 at the production map: conv3x3_ws, 3 tiles per persistent block
+                                       (6, 128, 384, 32),      # C = 32 at its production map (conv3x3_halo, persistent-prefetch variant)
+                                       (11, 100, 232, 32)])    # C = 32, >= 1024 ragged tiles
 def test_specialised_halo_variants_agree_with_gather(dev, N, Hh, Ww, C):
     """Every channel-specialised 3x3 kernel (compile-time K loop, software pipeline, LDS weights, register prefetch of the
     next tile, producer / consumer waves) against the plain gather kernel on the same operands: ReLU prologue + ReLU-mask
@@ -195,8 +197,8 @@ def test_ws_kernel_affine_prologue_and_event_statistics(dev):
     statistics, against conv3x3_halo on the same operands (the halo kernel itself is checked against fp32 PyTorch below)."""
     import _hip, ops
     torch.manual_seed(10)
-    C, N, E = 16, 8, 2
-    for rs, (Hs, Ws) in ((0, (128, 384)), (1, (64, 192))):
+    N, E = 8, 2
+    for C, rs, (Hs, Ws) in ((16, 0, (128, 384)), (16, 1, (64, 192)), (32, 0, (128, 384)), (32, 1, (64, 192))):
         Hh, Ww = (Hs, Ws) if rs == 0 else (2 * Hs, 2 * Ws)
         x = torch.randn(N, Hs, Ws, C, device=dev).to(BF)
         kpad = ops._kpad(9 * C)
@@ -213,8 +215,8 @@ def test_ws_kernel_affine_prologue_and_event_statistics(dev):
             ops._conv_launch(x, C, Hs, Ws, rs, sc, sh, C, True, N, Hh, Ww, C, C, 9, kpad, w, bias, None, 0, 0, 0, None, 0, None, out, st,
                              npe=N // E, flags=force)
             res.append((out, st.sum(1)))
-        close(res[0][0], res[1][0], 4e-3, f"rs={rs}: ws vs halo out")
-        close(res[0][1], res[1][1], 2e-3, f"rs={rs}: ws vs halo per-event stats")
+        close(res[0][0], res[1][0], 4e-3, f"C={C} rs={rs}: ws vs halo out")
+        close(res[0][1], res[1][1], 2e-3, f"C={C} rs={rs}: ws vs halo per-event stats")
         assert (res[0][1][0] - res[0][1][1]).abs().max() > 0       # the two events really have different statistics
 
 
@@ -515,6 +517,7 @@ def test_bn_finalize_matches_batch_norm(dev):
 
 @pytest.mark.parametrize("taps,C,Cout,Hh,Ww,N,res", [(9, 16, 16, 64, 96, 3, None),        # halo dgrad kernel (C = 16 variant)
                                                      (9, 16, 16, 128, 384, 6, None),      # conv3x3_ws dgrad kernel (>= 1024 tiles)
+                                                     (9, 32, 32, 128, 384, 6, None),      # C = 32 dgrad at its production map (conv3x3_halo)
                                                      (9, 64, 64, 16, 48, 3, None),        # halo dgrad kernel (C = 64)
                                                      (1, 64, 16, 32, 64, 3, None),        # gather dgrad kernel
                                                      (1, 32, 64, 128, 384, 3, "same"),    # streaming dgrad kernel + shortcut gradient
