@@ -297,7 +297,9 @@ def kernel_report(res, m, args):
                        "conv1x1_wgrad": "conv1x1_wgrad", "conv3x3_wgrad": "conv3x3_wgrad"}.get(fam)
                 if key:
                     got[key] += (r.get("bytes_min") or r["bytes"]) / prof_steps / 1e9
-            res["arch_calc_check"] = {k: {"calculator_gbytes": calc[k], "measured_launches_gbytes": got[k]} for k in calc}
+            res["arch_calc_check"] = {k: {"calculator_gbytes": calc[k], "measured_launches_gbytes": got[k]} for k in got}
+            for k in ("conv1x1_fwd_dgrad", "conv3x3_fwd_dgrad"):      # dgrad launches of resampled layers: both operands at the
+                res["arch_calc_check"][k]["calculator_gbytes_dgrad_as_launched"] = calc[k + "_as_launched"]      # layer's resolution
         except Exception as e:
             res["arch_calc_check"] = f"unavailable: {e}"
 

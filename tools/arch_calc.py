@@ -110,6 +110,12 @@ def step_family_gbytes():
         g, d = per_pass_bytes(G, kind), per_pass_bytes(D, kind)
         out[tag + "_fwd_dgrad"] = 2 * g + 3 * d + (g + 2 * d + d)          # forwards + dgrads (G full bwd, 2 D full, 1 D dgrad-only)
         out[tag + "_wgrad"] = g + 2 * d
+        # the same sum with every DGRAD launch taken as what it is: a convolution whose two operands both live at the layer's own
+        # resolution (the gradient w.r.t. an up-sampled / pooled source is folded back to the source resolution by the kernel
+        # behind it) -- this is the figure the launchers' per-launch 8(d) bytes add up to, to the byte
+        go = sum(l["bytes_out_res"] for l in G if l["taps"] == kind) / 1e9
+        do = sum(l["bytes_out_res"] for l in D if l["taps"] == kind) / 1e9
+        out[tag + "_fwd_dgrad_as_launched"] = 2 * g + 3 * d + (go + 2 * do + do)
     return out
 
 
