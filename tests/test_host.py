@@ -284,3 +284,16 @@ b(train_fns.test, G, D, E, sd, cfg, log)                                        
 assert callable(train_fns.dummy_training_function) and hasattr(model, "G_D")
 print("probe ok")
 """
+
+
+def test_integration_doc_stub_matches_the_binding():
+    """The ctypes stub printed in INTEGRATION.md declares the same fields, in the same order, as the binding the package uses
+    (a struct that is too short would read past its end on the device side of the call)."""
+    import re
+    import _hip
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for cls, ref in (("ConvDesc", _hip.ConvDesc), ("SrcDesc", _hip.SrcDesc)):
+        m = re.search(r"class %s\(C\.Structure\):\s*_fields_ = \[(.*?)\]\s" % cls, text, re.S)
+        assert m, cls
+        names = re.findall(r'\("(\w+)"', m.group(1))
+        assert names == [f[0] for f in ref._fields_], (cls, names)
