@@ -378,3 +378,42 @@ def test_data_parallel_path_single_rank_rehearsal(graph):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     rec = json.loads(r.stdout.strip().splitlines()[-1])
     assert rec["n_gpus"] == 1 and rec["value"] > 0 and all(np.isfinite(v) for v in rec["losses_last_step"].values()), rec
+
+
+def test_wgrad_side_stream_and_two_stage_accumulation_do_not_change_the_step():
+    """Weight-gradient launches on the side stream / two-stage accumulation (the defaults) against the plain form -- every launch
+    on one stream, float atomics -- on the same nets, event and noise: an ordering bug between the streams (a missing join or
+    record_stream) would show up as a different gradient.  At a map size (8 sensors at 256x768) where the large layers take the
+    two-stage path and several weight-gradient launches are in flight behind the dgrad chain; the flat gradient arenas still hold
+    the step's D-phase / G-phase gradients after ``train`` returns."""
+    import model, ops, train_fns, utils
+    from parity_util import O, build_product, make_cfg, make_noise, rel_l2
+    cfg = make_cfg(resolution=256, H_base=3, clip_norm=1e9, hip_graph=False, ema=False, batch_size=8)
+    x, y = O.synth_event(8, 256, 768, 404).cuda(), torch.arange(8).cuda()
+    noise = make_noise(8, 256, 768, 919)            # explicit draws: both runs consume identical numbers
+    results = []
+    for side, two in ((False, False), (True, True), (True, True)):
+        g_state, d_state = O.synth_nets(cfg, 111, 222)
+        G, D = build_product(cfg, g_state, d_state, "cuda:0")
+        z_, y_ = utils.prepare_z_y(8, G.dim_z, cfg["n_classes"], device="cuda:0")
+        train = train_fns.GAN_training_function(G, D, model.G_D(G, D), z_, y_, None, {"itr": 1}, cfg, "cuda:0")
+        keep = ops.WGRAD_SIDE_STREAM, ops.TWO_STAGE_WGRAD
+        ops.WGRAD_SIDE_STREAM, ops.TWO_STAGE_WGRAD = side, two
+        try:
+            out = train(x, y, noise=noise)
+            torch.cuda.synchronize()
+        finally:
+            ops.WGRAD_SIDE_STREAM, ops.TWO_STAGE_WGRAD = keep
+        results.append((out, G._arena.grad.clone(), D._arena.grad.clone()))
+    # Run-to-run noise of the SAME setting first (float atomics of the BatchNorm statistics make G(z) differ in its last bf16 bit;
+    # G's own gradient additionally sees D's Adam step, which amplifies that): B vs C.  Then A (plain) vs B (defaults).
+    (oa, ga, da), (ob, gb, db), (oc, gc, dc) = results
+    noise_g, noise_d = rel_l2(gc, gb), rel_l2(dc, db)
+    diff_g, diff_d = rel_l2(gb, ga), rel_l2(db, da)
+    print(json.dumps(dict(noise_g=noise_g, noise_d=noise_d, diff_g=diff_g, diff_d=diff_d)))
+    assert float(ga.norm()) > 0 and float(da.norm()) > 0
+    assert noise_d < 1e-2, noise_d                                  # the D-phase gradient is reproducible to rounding noise
+    assert diff_d <= 4.0 * noise_d + 1e-4, (diff_d, noise_d)        # ... and the stream / accumulation form does not move it further
+    assert diff_g <= 4.0 * noise_g + 1e-3, (diff_g, noise_g)
+    for k in oa:
+        assert abs(oa[k] - ob[k]) <= 2e-2 * max(1.0, abs(oa[k])), (k, oa[k], ob[k])
