@@ -7,6 +7,10 @@ typedef ieagan_src_desc SrcDesc;
 typedef ieagan_conv_desc ConvArgs;
 typedef ieagan_wgrad_desc WgradArgs;
 
+// internal bit of ConvArgs.flags (set by the launcher on its own copy of the descriptor, never by a caller): conv_gather splits the
+// K loop over the four waves of a block (tiny feature maps)
+#define CONV_INTERNAL_SPLITK (1 << 30)
+
 int conv_gather_launch(const ConvArgs& a, hipStream_t st);
 int conv_wgrad_launch(const WgradArgs& a, hipStream_t st, int use_tr);
 int conv3x3_lds_launch(const ConvArgs& a, hipStream_t st);       // 1 = launched, 0 = not applicable (caller falls back to conv3x3_halo), < 0 = error

@@ -37,7 +37,12 @@ __global__ __launch_bounds__(256, 4) void conv_gather_kernel(ConvArgs a) {
     const int lr = lane & 15, lg = lane >> 4;
     const int H = a.H, W = a.W, HW = H * W;
     const long M = (long)a.N * HW;
-    const long m_base = ((long)blockIdx.x * 4 + wave) * 32;
+    // Split-K form (launcher: tiny feature maps, NT == 1): the four waves of a block share ONE 32-pixel tile and take every fourth
+    // K step each -- a 4x12 / 8x24 map gives 15 / 60 blocks of 128 pixels whose single wave walks up to 36 dependent
+    // load -> MFMA steps with nothing else resident to hide them; split, the chain is a quarter as long and there are 4x the blocks.
+    const bool sk = NT == 1 && (a.flags & CONV_INTERNAL_SPLITK) != 0;
+    const int ppb = sk ? 32 : 128;                          // pixels per block
+    const long m_base = sk ? (long)blockIdx.x * 32 : ((long)blockIdx.x * 4 + wave) * 32;
     const int n_base = blockIdx.y * NT * 16;
 
     int pn[2], ph[2], pw[2];
@@ -59,7 +64,7 @@ __global__ __launch_bounds__(256, 4) void conv_gather_kernel(ConvArgs a) {
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     if (LAFF) {
-        stage_aff(aff_s, a.src, (int)(((long)blockIdx.x * 128) / HW), a.Cin);
+        stage_aff(aff_s, a.src, (int)(((long)blockIdx.x * ppb) / HW), a.Cin);
         __syncthreads();
     }
     const int ksteps = a.Kpad >> 5;
@@ -67,7 +72,7 @@ __global__ __launch_bounds__(256, 4) void conv_gather_kernel(ConvArgs a) {
     const bf16* wrow = (const bf16*)a.w + (long)(col_ok ? n_base + lr : 0) * a.Kpad + lg * 8;
     // (the bias stays a load inside the epilogue here: requested before the K loop it costs 8-12 VGPRs over the whole kernel and
     //  one to two resident waves per SIMD on most variants -- one tile per block, the other blocks hide that latency)
-    for (int ks = 0; ks < ksteps; ++ks) {
+    for (int ks = sk ? wave : 0; ks < ksteps; ks += sk ? 4 : 1) {
         const int k = ks * 32 + lg * 8;
         int tap = 0, c = k;
         if (TAPS == 9) {
@@ -95,6 +100,26 @@ __global__ __launch_bounds__(256, 4) void conv_gather_kernel(ConvArgs a) {
     float s1[8], s2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
+    if (NT == 1 && sk) {           // fold the four partial accumulators into wave 0 through the (not yet used) epilogue buffer
+        float* part = epi;         // [3 waves][8 values][64 lanes]: 6 KB of the 10 KB buffer
+        if (wave > 0) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part[((wave - 1) * 8 + mt * 4 + r) * 64 + lane] = acc[mt][0][r];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int w = 0; w < 3; ++w)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[mt][0][r] += part[(w * 8 + mt * 4 + r) * 64 + lane];
+        }
+        // (wave 0 reads before it writes its own region of the buffer below: same wave, in order)
+    }
+    const bool epi_wave = !sk || wave == 0;
     const bool need_hw = (a.ra != nullptr && a.ra_rs != 0) || (BNB && a.bnb_scale != nullptr);
     auto pix = [&](int row, long& m, int& n, int& h, int& w) -> bool {
         m = m_base + row;
@@ -116,21 +141,22 @@ __global__ __launch_bounds__(256, 4) void conv_gather_kernel(ConvArgs a) {
             conv_epilogue<BNB, NT, 1, (RS != 2)>(a, sub, epi + wave * EROWS * EpiLds<NT>::LDW, n_base, pixh, s1, s2);      // (pooled-source variants: no registers to spare)
         }
     } else {
-        conv_epilogue<BNB, NT, 2, (RS != 2)>(a, acc, epi + wave * EROWS * EpiLds<NT>::LDW, n_base, pix, s1, s2);
+        if (epi_wave) conv_epilogue<BNB, NT, 2, (RS != 2)>(a, acc, epi + wave * EROWS * EpiLds<NT>::LDW, n_base, pix, s1, s2);
     }
     static_assert(4 * EROWS * EpiLds<NT>::LDW >= 4 * STATS_SX_FLOATS, "epilogue buffer doubles as the statistics scratch");
     if (a.stats != nullptr) {
         __syncthreads();          // every wave is done with its part of the epilogue buffer, which now serves as fold scratch
         // every 128-pixel block lies inside one event (launcher: n_per_event * H * W % 128 == 0 when E > 1)
-        const int event = (a.n_per_event > 0) ? (int)(((long)blockIdx.x * 128) / ((long)a.n_per_event * HW)) : 0;
+        const int event = (a.n_per_event > 0) ? (int)(((long)blockIdx.x * ppb) / ((long)a.n_per_event * HW)) : 0;
         stats_flush<NT>(a, s1, s2, n_base, red, epi, blockIdx.x, event);
     }
 }
 
 template <int TAPS, bool AFF, bool RELU, int RS, bool BNB = false>
-static int launch_gather_nt(const ConvArgs& a, hipStream_t st) {
+static int launch_gather_nt(const ConvArgs& a0, hipStream_t st) {
+    ConvArgs a = a0;
     const long M = (long)a.N * a.H * a.W;
-    const unsigned gx = (unsigned)((M + 127) / 128);
+    unsigned gx = (unsigned)((M + 127) / 128);
     // tiny feature maps (4x12 ... 16x48): split the output channels over more blocks to cover the chip
     const bool small4 = (long)gx * (a.Cout / 64) < 512, small2 = (long)gx * (a.Cout / 32) < 512;
     // affine table in LDS when every 128-pixel block lies inside one image (all but the tiniest maps)
@@ -142,7 +168,16 @@ static int launch_gather_nt(const ConvArgs& a, hipStream_t st) {
     }
     if (a.Cout % 64 == 0 && !small4) GATHER_LAUNCH(4, a.Cout / 64)
     else if (a.Cout % 32 == 0 && !(small4 && small2 && a.Cout % 64 == 0)) GATHER_LAUNCH(2, a.Cout / 32)
-    else GATHER_LAUNCH(1, (a.Cout + 15) / 16)
+    else {
+        // tiny maps with a long K loop: split K over the waves of a block (conv_gather_kernel: sk); per-event statistics need
+        // whole 32-pixel blocks per event
+        const bool ev_ok = !(a.stats != nullptr && a.n_per_event > 0 && a.n_per_event < a.N) || ((long)a.n_per_event * a.H * a.W) % 32 == 0;
+        if (M <= 32768 && (a.Kpad >> 5) >= 8 && ev_ok && !(a.flags & IEAGAN_CONV_FORCE_GATHER)) {
+            a.flags |= CONV_INTERNAL_SPLITK;
+            gx = (unsigned)((M + 31) / 32);
+        }
+        GATHER_LAUNCH(1, (a.Cout + 15) / 16)
+    }
 #undef GATHER_LAUNCH
     return 0;
 }
@@ -503,6 +538,7 @@ static int launch_halo_pro(const ConvArgs& a, hipStream_t st) {
 
 int conv_gather_launch(const ConvArgs& a, hipStream_t st) {
     CHECK_ARG(a.taps == 1 || a.taps == 9, "conv: taps must be 1 or 9 (got %d)", a.taps);
+    CHECK_ARG((a.flags & ~(IEAGAN_CONV_FORCE_GATHER | IEAGAN_CONV_NO_LDS_WEIGHTS | IEAGAN_CONV_FP8)) == 0, "conv: unknown flag bits 0x%x", a.flags);
     CHECK_ARG(a.Cin % 8 == 0 && a.Cout % 8 == 0, "conv: Cin/Cout must be multiples of 8 (%d,%d)", a.Cin, a.Cout);
     CHECK_ARG(a.Kpad % 32 == 0 && a.Kpad >= a.taps * a.Cin, "conv: bad Kpad %d", a.Kpad);
     CHECK_ARG(a.src.rs >= 0 && a.src.rs <= 2, "conv: bad resample mode %d", a.src.rs);

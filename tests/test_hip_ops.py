@@ -769,3 +769,34 @@ def test_event_ingest_and_frechet_distance(dev, golden_dir):
         fd = utils.frechet_distance(m1, s1, m2, s2)
         ref = float(f["fd_" + name])
         assert abs(fd - ref) <= 1e-5 * max(1.0, abs(ref)), (name, fd, ref)
+
+
+@pytest.mark.parametrize("taps,Cin,Cout,Hh,Ww,N,events", [(1, 512, 128, 8, 24, 40, 1),     # G b2/b3 conv1 at 8x24
+                                                          (1, 512, 128, 4, 12, 40, 2),     # ... at 4x12 (48 pixels per image), two events
+                                                          (1, 256, 64, 16, 48, 40, 1),     # 16x48
+                                                          (9, 128, 128, 4, 12, 40, 1),     # 3x3 on the 4x12 map: 36 K steps
+                                                          (9, 32, 16, 6, 10, 7, 1)])       # ragged: 420 pixels, half-empty n-tile
+def test_split_k_gather_matches_plain_gather(dev, taps, Cin, Cout, Hh, Ww, N, events):
+    """conv_gather's split-K form (tiny maps: the four waves of a block share one 32-pixel tile and a quarter of the K steps each)
+    against the plain form (FORCE_GATHER) on the same operands: ccbn prologue, mask, statistics per event."""
+    import _hip, ops
+    torch.manual_seed(17)
+    x = torch.randn(N, Hh, Ww, Cin, device=dev).to(BF)
+    kpad = ops._kpad(taps * Cin)
+    w = torch.zeros(Cout, kpad, device=dev)
+    w[:, :taps * Cin] = torch.randn(Cout, taps * Cin, device=dev) / math.sqrt(taps * Cin)
+    w = w.to(BF)
+    bias = 0.1 * torch.randn(Cout, device=dev)
+    sc = 1 + 0.2 * torch.randn(N, Cin, device=dev)
+    sh = 0.2 * torch.randn(N, Cin, device=dev)
+    mask = torch.randn(N, Hh, Ww, Cout, device=dev).to(BF)
+    res = []
+    npe = N // events if (N % events == 0 and ((N // events) * Hh * Ww) % 128 == 0) else 0
+    for force in (0, _hip.CONV_FORCE_GATHER):
+        out = torch.empty(N, Hh, Ww, Cout, device=dev, dtype=BF)
+        st = ops.new_stats(Cout, dev, events if npe else 1)
+        ops._conv_launch(x, Cin, Hh, Ww, 0, sc, sh, Cin, True, N, Hh, Ww, Cin, Cout, taps, kpad, w, bias, None, 0, 0, 0, None, 0, mask, out, st,
+                         npe=npe, flags=force)
+        res.append((out, st.sum(1)))
+    close(res[0][0], res[1][0], 4e-3, "split-K vs plain gather out")          # fp32 partial sums added in a different order
+    close(res[0][1], res[1][1], 2e-3, "split-K vs plain gather statistics")

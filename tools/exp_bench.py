@@ -2,6 +2,9 @@
 import os, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(root, "iea-gan_amd"), root]
+import _hip
+if os.environ.get("IEAGAN_LIB"):          # A/B of two builds on the same box
+    _hip.LIB_PATH = os.environ["IEAGAN_LIB"]
 import ops
 for kv in os.environ.get("EXP", "").split(","):
     if kv:
