@@ -12,4 +12,14 @@ for kv in os.environ.get("EXP", "").split(","):
         assert hasattr(ops, k), k
         setattr(ops, k, eval(v))
 import bench
+if os.environ.get("CFG"):                  # CFG=sn_prefetch=False,... : overrides of the benchmark's train configuration
+    _base = bench.bench_config
+
+    def _patched(*a, **k):
+        cfg = _base(*a, **k)
+        for kv in os.environ["CFG"].split(","):
+            key, val = kv.split("=")
+            cfg[key] = eval(val)
+        return cfg
+    bench.bench_config = _patched
 bench.main()
