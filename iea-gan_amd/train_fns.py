@@ -158,11 +158,15 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
     # Spectral-norm passes ahead of time on a side stream (ops.SNBank.prefetch): 4 of the 5 passes of a step depend on weights
     # that are final long before the forward that consumes them.  Single-GPU default step only (split_D, no accumulation): the
     # number of forward passes per phase is then known -- G: 1 + 1, D: 2 (+1 with Con_reg) + 1.
-    sn_ahead = bool(config.get("sn_prefetch", True)) and sync is None and config["split_D"] and config["num_D_steps"] == 1 and \
+    sn_known = bool(config.get("sn_prefetch", True)) and config["split_D"] and config["num_D_steps"] == 1 and \
         config["num_D_accumulations"] == 1 and config["num_G_accumulations"] == 1 and contra
+    sn_ahead = sn_known and sync is None
+    # Data parallel: the step is three graphs with eager all-reduces between them, and a pass issued in one graph cannot be handed to
+    # the next -- only the passes that are issued AND consumed inside the D phase go ahead (3 of the step's 5).
+    sn_local = sn_known and sync is not None
 
-    def prefetch_sn(net, passes):
-        if not sn_ahead or not next(net.parameters()).is_cuda:
+    def prefetch_sn(net, passes, local=False):
+        if not (sn_ahead or (local and sn_local)) or not next(net.parameters()).is_cuda:
             return
         if st.get("sn_stream") is None:
             st["sn_stream"] = torch.cuda.Stream()
@@ -174,8 +178,11 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
     def d_forward_backward():
         """Zero both gradient arenas, accumulate D's gradient (train_fns.py:24-130); returns [real, fake, unif_d]."""
         x, y = st["x"], st["y"]
-        prefetch_sn(G, 2)                       # both generator passes of the step: G's weights only change in g_update
-        prefetch_sn(D, 3 if config["Con_reg"] else 2)      # D(fake), D(real)[, D(real_aug)]: D's weights change in d_update
+        if sn_local:
+            prefetch_sn(G, 1, local=True)       # this phase's generator pass
+        else:
+            prefetch_sn(G, 2)                   # both generator passes of the step: G's weights only change in g_update
+        prefetch_sn(D, 3 if config["Con_reg"] else 2, local=True)      # D(fake), D(real)[, D(real_aug)]: D's weights change in d_update
         G.optim.zero_grad()
         D.optim.zero_grad()
         x_aug = None
