@@ -255,6 +255,9 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
             utils.toggle_grad(D, False)
             utils.toggle_grad(G, True)
         G.optim.zero_grad()
+        if sn_local:
+            sync.wait("D")                      # D's update (side stream) precedes the spectral-norm pass of the D evaluation below,
+            prefetch_sn(D, 1, local=True)       # which then runs under the generator forward
         iea_loss = zero
         for _ in range(config["num_G_accumulations"]):
             c = st["counter"]
