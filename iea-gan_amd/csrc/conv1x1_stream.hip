@@ -292,7 +292,7 @@ int conv1x1_stream_launch(const ConvArgs& a, hipStream_t st) {
     const long HW = (long)a.H * a.W, M = (long)a.N * HW;
     const int mt = (a.Cin <= 16 && a.Cout % 64 != 0) ? 4 : 2;
     const int gp = 4 * mt * 16;
-    if (HW % gp != 0 || M / gp < 1024) return 0;                   // large maps only: >= 4 groups per CU
+    if (HW % gp != 0 || M / gp < 480) return 0;                    // >= 480 pixel groups (32x96 maps and larger)
     if (a.src.scale != nullptr && a.Cin > AFF_MAXC) return 0;
     if (a.ra && a.ra_rs == 1 && (a.H % 2 || a.W % 2)) return 0;
     const bool aff = a.src.scale != nullptr, relu = a.src.relu != 0;
