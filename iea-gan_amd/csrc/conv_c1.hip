@@ -28,25 +28,6 @@ __global__ __launch_bounds__(256) void conv_1toC_kernel(const float* __restrict_
     __shared__ __attribute__((aligned(16))) float ot[4][16 * LDO];   // per wave: one m-tile (16 pixels) x C channels
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 15, lg = lane >> 4;
-    const int tile = blockIdx.x;
-    const int n = tile / (tiles_w * tiles_h);
-    const int trem = tile - n * tiles_w * tiles_h;
-    const int y0 = (trem / tiles_w) * I1_TH, x0 = (trem % tiles_w) * I1_TW;
-    const float* im = img + (size_t)n * H * W;
-    const float* ty_ = tanh_y ? tanh_y + (size_t)n * H * W : nullptr;
-    for (int i = threadIdx.x; i < AH * AW; i += 256) {
-        const int qy = i / AW, qx = i - qy * AW;
-        const int yy = y0 - 1 + qy, xx = x0 - 1 + qx;
-        float v = 0.f;
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-            v = im[yy * W + xx];
-            if (ty_) {
-                const float t = ty_[yy * W + xx];
-                v *= 1.f - t * t;
-            }
-        }
-        halo[qy][qx] = v;
-    }
     // B fragments: B[k][cout lr]; k slots 8*lg + j: lg 0 -> taps 0..7, lg 1 -> tap 8 (j = 0), lg 2 / 3 the same again (low parts)
     bf16x8 bfrag[NT];
 #pragma unroll
@@ -62,6 +43,30 @@ __global__ __launch_bounds__(256) void conv_1toC_kernel(const float* __restrict_
     const int cc = lane % (C / 8);                               // this lane's 8-channel chunk in the store phase
 #pragma unroll
     for (int i = 0; i < 8; ++i) bv[i] = bias ? bias[cc * 8 + i] : 0.f;
+    // persistent blocks: the weight fragments and the bias are fetched once, a block walks consecutive tiles
+    const int ntiles = N * tiles_w * tiles_h;
+    const int per = (ntiles + gridDim.x - 1) / gridDim.x;
+    const int tile_end = min((int)(blockIdx.x + 1) * per, ntiles);
+    for (int tile = blockIdx.x * per; tile < tile_end; ++tile) {
+    const int n = tile / (tiles_w * tiles_h);
+    const int trem = tile - n * tiles_w * tiles_h;
+    const int y0 = (trem / tiles_w) * I1_TH, x0 = (trem % tiles_w) * I1_TW;
+    const float* im = img + (size_t)n * H * W;
+    const float* ty_ = tanh_y ? tanh_y + (size_t)n * H * W : nullptr;
+    __syncthreads();                                             // the previous tile's halo has been consumed
+    for (int i = threadIdx.x; i < AH * AW; i += 256) {
+        const int qy = i / AW, qx = i - qy * AW;
+        const int yy = y0 - 1 + qy, xx = x0 - 1 + qx;
+        float v = 0.f;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+            v = im[yy * W + xx];
+            if (ty_) {
+                const float t = ty_[yy * W + xx];
+                v *= 1.f - t * t;
+            }
+        }
+        halo[qy][qx] = v;
+    }
     __syncthreads();
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {                             // wave: tile rows 2*wave, 2*wave+1 = 4 m-tiles of 16 pixels
@@ -104,6 +109,7 @@ __global__ __launch_bounds__(256) void conv_1toC_kernel(const float* __restrict_
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");      // the next m-tile overwrites the buffer
         __builtin_amdgcn_wave_barrier();
     }
+    }
 }
 
 extern "C" int ieagan_conv_1toC(const float* img, const float* tanh_y, const float* w, const float* bias, void* out, int N,
@@ -111,8 +117,9 @@ extern "C" int ieagan_conv_1toC(const float* img, const float* tanh_y, const flo
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof("conv_1toC", 18.0 * N * H * W * (double)C, (double)N * H * W * (4.0 + 2.0 * C), st);
     const int tiles_w = (W + I1_TW - 1) / I1_TW, tiles_h = (H + I1_TH - 1) / I1_TH;
-    const long blocks = (long)N * tiles_w * tiles_h;
-    CHECK_ARG(blocks > 0 && blocks < (1L << 31), "conv_1toC: bad geometry");
+    const long ntl = (long)N * tiles_w * tiles_h;
+    CHECK_ARG(ntl > 0 && ntl < (1L << 31), "conv_1toC: bad geometry");
+    const long blocks = ntl < 4096 ? ntl : 4096;                 // persistent: ~16 blocks per CU, several tiles each
 #define L(CC) hipLaunchKernelGGL((conv_1toC_kernel<CC>), dim3((unsigned)blocks), dim3(256), 0, st, img, tanh_y, w, bias, (bf16*)out, N, H, W, flip, tiles_w, tiles_h)
     if (C == 16) L(16);
     else if (C == 32) L(32);
