@@ -387,7 +387,10 @@ class Discriminator(nn.Module):
             ar, self._plan = Arena(self), None
         if self._plan is not None and self._plan["arena"] is ar:
             return self._plan
-        entries = [(n, m._sn_kind, m.weight, m.u0, m.sv0) for n, m in _sn_children(self, "")]
+        # only the layers a forward pass evaluates take part in the power iteration: the projection head never touches RR_D
+        # (constructed whenever RRM_embed, reference model.py:788-798, 939-944), whose u0 / sv0 must then stay put
+        used = lambda n: self.conditional_strategy == "Contra" or not n.startswith("RR_D.")
+        entries = [(n, m._sn_kind, m.weight, m.u0, m.sv0) for n, m in _sn_children(self, "") if used(n)]
         self._plan = dict(arena=ar, bank=ops.SNBank(ar.flat, entries, owner=ar, biases=_sn_biases(self)))
         return self._plan
 

@@ -69,6 +69,8 @@ class FusedAdam(torch.optim.Optimizer):
         elif self._m.numel() != n:
             raise RuntimeError(f"FusedAdam: optimizer state holds {self._m.numel()} elements, the network's arena {n}")
         elif self._m.device != a.flat.device:       # network moved after the state was created / loaded: follow it
+            if self._hp is not None:                # the device counter hp[4] is authoritative (graph replays never touch the mirror)
+                self._step = int(self._hp[4].item())
             self._m, self._v, self._hp = self._m.to(a.flat.device), self._v.to(a.flat.device), None
             self.push_hyper()
         if not torch.cuda.is_current_stream_capturing():

@@ -108,6 +108,9 @@ def run(cfg):
             os.makedirs(os.path.join(run_dir, sub), exist_ok=True)
     if cfg["resume"]:
         utils.load_weights(G, D, state, cfg, cfg.get("load_weights") or None, G_ema, load_optim=cfg["load_optim"])
+        for net in (G, D):              # fast-forward the lr schedules to the restored epoch (reference train.py:91-94)
+            if net.lr_sched is not None:
+                net.lr_sched.step(state["epoch"])
     if world > 1:
         # every replica starts from rank 0's state: G, D and the EMA copy (one flat arena each -> one broadcast each)
         for net in (G, D):
@@ -134,10 +137,15 @@ def run(cfg):
     if per_rank == 0:
         raise SystemExit(f"{len(events)} event(s) cannot be sharded over {world} ranks (need at least one per rank)")
     mine = [events[i] for i in parallel.shard_events(len(events), rank, world)][:per_rank]
-    z_, y_ = utils.prepare_z_y(max(cfg["G_batch_size"], cfg["batch_size"]), G.dim_z, cfg["n_classes"], device=dev,
+    # E events per step (events_per_step): every step consumes E events of this rank's shard, batched on the leading
+    # dimension; a trailing group of fewer than E events is dropped (like DataLoader(drop_last=True))
+    E = max(int(cfg.get("events_per_step", 1) or 1), 1)
+    if len(mine) < E:
+        raise SystemExit(f"events_per_step={E} but this rank holds only {len(mine)} event(s)")
+    z_, y_ = utils.prepare_z_y(max(cfg["G_batch_size"], cfg["batch_size"]) * E, G.dim_z, cfg["n_classes"], device=dev,
                                z_dist=cfg["z_dist"], threshold=cfg["truncated_threshold"])
     train = train_fns.GAN_training_function(G, D, GD, z_, y_, ema, state, cfg, dev)
-    y = torch.arange(cfg["n_classes"], device=dev)
+    y = torch.arange(cfg["n_classes"], device=dev).repeat(E)
     log = open(os.path.join(lroot, f"metrics_rank{rank}.jsonl"), "a") if rank == 0 else None
     t0 = time.time()
 
@@ -149,14 +157,15 @@ def run(cfg):
     stop = False
     for epoch in range(state["epoch"], cfg["num_epochs"]):
         order = np.random.permutation(len(mine)) if cfg["shuffle"] else np.arange(len(mine))
-        for i in order:
+        for s0 in range(0, len(order) - E + 1, E):
             state["itr"] += 1
             G.train()
             D.train()
             if G_ema is not None:
                 G_ema.train()
-            ev = mine[i] if isinstance(mine[i], np.ndarray) else np.load(mine[i])
-            x = to_network_range(torch.from_numpy(ev), h).to(dev)
+            evs = [mine[i] if isinstance(mine[i], np.ndarray) else np.load(mine[i]) for i in order[s0:s0 + E]]
+            x = torch.cat([to_network_range(torch.from_numpy(ev), h).to(dev) for ev in evs]) if E > 1 else \
+                to_network_range(torch.from_numpy(evs[0]), h).to(dev)
             metrics = train(x, y)
             if log is not None:
                 rec = dict(itr=state["itr"], **metrics)
@@ -173,12 +182,12 @@ def run(cfg):
             if cfg["max_iters"] and state["itr"] >= cfg["max_iters"]:
                 stop = True
                 break
+        if stop:                        # max_iters reached mid-epoch: the partial epoch neither counts nor steps the schedules
+            break
         state["epoch"] += 1
         for net in (G, D):
             if net.lr_sched is not None:
                 net.lr_sched.step()
-        if stop:
-            break
     checkpoint()
     if rank == 0:
         print(f"done: {state['itr']} iterations, weights under {os.path.join(run_dir, 'weights')}")

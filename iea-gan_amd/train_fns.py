@@ -175,6 +175,17 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
             bank.prefetch(net.training, net.SN_eps, st["sn_stream"])
 
     # ------------------------------------------------------------------------------------------------ D phase
+    def check_shapes(x, y):
+        """One pass consumes ``chunk`` = batch_size * events_per_step images (the reference: one event); ``x`` holds one
+        chunk per G accumulation (``torch.split(x, chunk)`` indexed by the G-phase counter, train_fns.py:34-37, 182).  A short batch
+        would silently run ``loss_block`` on empty per-event slices: refuse it here."""
+        n_acc = max(int(config["num_G_accumulations"]), 1)
+        if x.shape[0] % chunk != 0 or x.shape[0] // chunk < n_acc or y.shape[0] != x.shape[0]:
+            raise ValueError(f"train(x, y): expected a multiple (>= {n_acc}) of {chunk} images and as many labels per step "
+                             f"(batch_size {bs} x events_per_step {E}), got x {tuple(x.shape)}, y {tuple(y.shape)}")
+        if z_.shape[0] < chunk:
+            raise ValueError(f"z_ holds {z_.shape[0]} latent rows, one pass needs {chunk} (prepare_z_y(batch_size * events_per_step, ...))")
+
     def d_forward_backward():
         """Zero both gradient arenas, accumulate D's gradient (train_fns.py:24-130); returns [real, fake, unif_d]."""
         x, y = st["x"], st["y"]
@@ -327,7 +338,16 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
         return torch.stack([gv[0], dv[0], dv[1], dv[2], gv[1]])
 
     def whole_step():
-        return step_tensor(d_forward_backward, g_forward_backward, g_update)
+        try:
+            return step_tensor(d_forward_backward, g_forward_backward, g_update)
+        except BaseException:
+            # a step that ends early must not leave spectral-norm passes queued: the next forward would silently consume a pass
+            # computed from older weights / an older u (every later step shifted by one pass)
+            for net in (G, D):
+                plan = getattr(net, "_plan", None)
+                if plan is not None:
+                    plan["bank"].discard_prefetched()
+            raise
 
     use_graph = bool(config.get("hip_graph", False))
     whole = _Replay(whole_step)
@@ -341,6 +361,7 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
 
     def train(x, y, noise=None):
         """The reference's ``train(x, y) -> dict of 5 python floats`` (ONE host sync, at the end)."""
+        check_shapes(x, y)
         if not use_graph or noise is not None:
             st["x"], st["y"], st["noise"] = x, y, noise
             vals = whole_step()
@@ -353,6 +374,11 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
         st["x"].copy_(x)
         st["y"].copy_(y)
         st["noise"] = None
+        if sync is not None:
+            # the previous step's side-stream Adam / EMA still READ the lr / decay block that the push below rewrites on the
+            # main stream: join them first, or which step sees a new value is timing-dependent per rank (replicas diverge)
+            sync.wait("D")
+            sync.wait("G")
         push_device_state()                               # lr / decay changes reach the graphs through device memory
         vals = whole() if sync is None else step_tensor(*seg, replayed=True)
         return dict(zip(KEYS, vals.tolist()))

@@ -448,6 +448,35 @@ def _d_phase_loss(ts: TrainState, x: Tensor, y: Tensor, noise: dict):
         gz = generator(g, cfg, noise["z_d"], y, noise["rdof_d"], True)
         if cfg.get("diff_aug", True):
             gz = diff_augment(gz, noise["aug_d"])
+    if cfg["conditional_strategy"] != "Contra":                                    # Proj: train_fns.py:55-77, model.py:1009-1013
+        d_fake = discriminator(d, cfg, gz, y, True)
+        d_real = discriminator(d, cfg, x, y, True)
+        l_real, l_fake = hinge_dis(d_fake, d_real)
+        d_loss = l_real + l_fake
+        if cfg.get("Con_reg", False):
+            d_real_a = discriminator(d, cfg, cr_diff_augment(x, noise["cr"]), y, True)
+            d_loss = d_loss + cfg["cr_lambda"] * l2_loss(d_real, d_real_a)
+        return d_loss, (l_real, l_fake, zero), None
+    if not cfg.get("split_D", True):
+        # joint pass (model.py:1024-1068): D sees cat[G_z, x(, x_aug)] as ONE batch -- RR_D then relates all 2n (3n) tokens
+        parts, labels = [gz, x], [y, y]
+        if cfg.get("Con_reg", False):
+            parts.append(cr_diff_augment(x, noise["cr"]))
+            labels.append(y)
+        n = y.shape[0]
+        proxy, emb, out = discriminator(d, cfg, torch.cat(parts), torch.cat(labels), True)
+        d_fake, d_real, proxy_r, emb_r = out[:n], out[n:2 * n], proxy[n:2 * n], emb[n:2 * n]
+        l_real, l_fake = hinge_dis(d_fake, d_real)
+        d_loss = l_real + l_fake
+        if cfg.get("contra_lambda", 1.0) != 0:
+            d_loss = d_loss + cfg["contra_lambda"] * contrastive_loss(emb_r, proxy_r)
+        unif_d = zero
+        if cfg.get("Uniformity_loss", False):
+            unif_d = unif_loss(emb_r)
+            d_loss = d_loss + cfg["unif_lambda"] * unif_d
+        if cfg.get("Con_reg", False):                                              # train_fns.py:93-102 (+ uniformity, as in split mode)
+            d_loss = d_loss + cfg["cr_lambda"] * (l2_loss(d_real, out[2 * n:]) + l2_loss(emb_r, emb[2 * n:]))
+        return d_loss, (l_real, l_fake, unif_d), emb_r.detach()
     proxy_f, emb_f, d_fake = discriminator(d, cfg, gz, y, True)                    # model.py:987
     proxy_r, emb_r, d_real = discriminator(d, cfg, x, y, True)                     # model.py:1002
     l_real, l_fake = hinge_dis(d_fake, d_real)
@@ -468,6 +497,12 @@ def _d_phase_loss(ts: TrainState, x: Tensor, y: Tensor, noise: dict):
 def _g_phase_loss(ts: TrainState, y: Tensor, noise: dict, emb_r: Tensor):
     """G-phase loss of ONE event (train_fns.py:150-181)."""
     cfg, g, d = ts.cfg, ts.g, ts.d
+    if cfg["conditional_strategy"] != "Contra":       # Proj (train_fns.py:152-157): G is driven with the label vector y_ ('y_g')
+        yg = noise.get("y_g", y)
+        gz = generator(g, cfg, noise["z_g"], yg, noise["rdof_g"], True)
+        if cfg.get("diff_aug", True):
+            gz = diff_augment(gz, noise["aug_g"])
+        return hinge_gen(discriminator(d, cfg, gz, yg, True)), torch.zeros(())
     gz = generator(g, cfg, noise["z_g"], y, noise["rdof_g"], True)
     if cfg.get("diff_aug", True):
         gz = diff_augment(gz, noise["aug_g"])
@@ -707,11 +742,11 @@ def d_spec(cfg) -> Dict[str, tuple]:
     c_top = stages[-1][3]
     hyp = cfg.get("hypersphere_dim", 512)
     _sn(spec, "linear0", 1, (c_top,))
+    if cfg.get("RRM_embed", False):                  # constructed for either head (model.py:788-798); only Contra evaluates it
+        _rrm_spec(spec, "RR_D", c_top, 512, sn=True)
+        spec["norm.weight"] = (hyp,)
+        spec["norm.bias"] = (hyp,)
     if cfg["conditional_strategy"] == "Contra":
-        if cfg.get("RRM_embed", False):
-            _rrm_spec(spec, "RR_D", c_top, 512, sn=True)
-            spec["norm.weight"] = (hyp,)
-            spec["norm.bias"] = (hyp,)
         _sn(spec, "linear1", hyp, (c_top,))
         _sn(spec, "embed", cfg["n_classes"], (hyp,), bias=False, n_u=cfg["n_classes"])
     else:

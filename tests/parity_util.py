@@ -99,7 +99,7 @@ def _flat_grads(net, grads):
 
 
 def step_parity(resolution=64, H_base=1, device="cuda:0", verbose=False, n=40, events=1, state_check=False, oracle_bf16=False,
-                inputs=None, **cfg_over):
+                inputs=None, y_g=None, **cfg_over):
     """One full train(x, y) on the HIP path vs the oracle on identical weights / noise: the 5 losses and the flat G / D
     gradients (cosine, rel-L2); with ``state_check`` also the post-step state (parameters after Adam, spectral-norm
     ``u0`` / ``sv0``, BatchNorm running statistics).  ``n`` < 40 runs a sub-event of the first n sensors (full
@@ -117,10 +117,14 @@ def step_parity(resolution=64, H_base=1, device="cuda:0", verbose=False, n=40, e
     G, D = build_product(cfg, g_state, d_state, device)
     GD = model.G_D(G, D)
     z_, y_ = utils.prepare_z_y(n * events, G.dim_z, cfg["n_classes"], device=device)
+    if y_g is not None:                 # projection strategy: the label vector the G phase feeds (train_fns.py:153), explicit
+        y_ = y_g.to(device)
     train = train_fns.GAN_training_function(G, D, GD, z_, y_, None, {"itr": 1}, cfg, device)
     y = torch.arange(n)
     if inputs is not None:              # events + draws of a committed fixture
         xs, noises = inputs
+        if y_g is not None:
+            noises = [dict(nz, y_g=y_g) for nz in noises]
     else:
         xs = [O.synth_event(n, hh, ww, 303 + e) for e in range(events)]
         noises = [make_noise(n, hh, ww, 909 + e) for e in range(events)]

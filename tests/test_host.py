@@ -167,6 +167,26 @@ def test_train_entry_point_config_merge(tmp_path):
         train.parse(["--no_such_option", "1"])
 
 
+def test_train_step_rejects_batches_that_are_not_whole_events(ref_cfg):
+    """``events_per_step = E``: one step consumes E * batch_size images; a single event handed to an E = 2 train function (what
+    train.py did before it grouped events) must raise instead of running the loss block on empty per-event slices."""
+    import io, contextlib
+    import model, train_fns, utils
+    cfg = dict(ref_cfg, device="cpu", resolution=64, H_base=1, events_per_step=2, ema=False)
+    with contextlib.redirect_stdout(io.StringIO()):
+        G, D = model.Generator(**cfg), model.Discriminator(**cfg)
+    z_, y_ = utils.prepare_z_y(80, G.dim_z, cfg["n_classes"], device="cpu")
+    train = train_fns.GAN_training_function(G, D, model.G_D(G, D), z_, y_, None, {"itr": 0}, cfg, "cpu")
+    with pytest.raises(ValueError, match="multiple"):
+        train(torch.zeros(40, 1, 64, 64), torch.arange(40))
+    with pytest.raises(ValueError, match="labels"):
+        train(torch.zeros(80, 1, 64, 64), torch.arange(40))
+    z_small, _ = utils.prepare_z_y(40, G.dim_z, cfg["n_classes"], device="cpu")
+    train2 = train_fns.GAN_training_function(G, D, model.G_D(G, D), z_small, y_, None, {"itr": 0}, cfg, "cpu")
+    with pytest.raises(ValueError, match="latent rows"):
+        train2(torch.zeros(80, 1, 64, 64), torch.arange(40).repeat(2))
+
+
 def test_adam_state_interchanges_with_torch_optim_adam(ref_cfg):
     """G_optim.pth / D_optim.pth are in torch.optim.Adam's own state-dict format in both directions (the reference
     builds optim.Adam over the same parameter order, model.py:410-416, 858-864)."""
@@ -227,6 +247,37 @@ def test_checkpoint_files_follow_reference_layout(tmp_path, ref_cfg, golden_dir)
     svs = utils.get_singular_values(G, "G")
     contract = json.load(open(os.path.join(golden_dir, "state_dict_contract.json")))["G_64x64"]["keys"]
     assert set(svs) == {f"G_{k}".replace(".", "_") for k in contract if "sv" in k} and "G_linear_sv0" in svs
+
+
+def test_checkpoint_written_by_the_reference_loads(golden_dir, ref_cfg, tmp_path):
+    """``tests/golden/ckpt_ref/run/weights/*.pth`` was written by the REFERENCE's ``utils.save_weights`` (reference
+    utils/__init__.py:689-726; tests/golden/make_golden_r3.py, tiny G_ch = D_ch = 2 networks).  This package's
+    ``utils.load_weights`` must read it: every state-dict entry equal to the reference's (per-key checksums from the same
+    script), the iteration counters restored, the (empty) reference-format optimizer state accepted."""
+    import io, contextlib, shutil
+    import numpy as np
+    import model, utils
+    src = os.path.join(golden_dir, "ckpt_ref")
+    shutil.copytree(src, tmp_path / "out")
+    cfg = dict(ref_cfg, device="cpu", resolution=64, H_base=1, G_ch=2, D_ch=2, dim_z=8, hypersphere_dim=32, ema=False,
+               outputroot=str(tmp_path / "out"), run_name="run")
+    sums = np.load(os.path.join(golden_dir, "ckpt_ref.npz"))
+    assert sorted(sums["files"].tolist()) == sorted(os.listdir(tmp_path / "out" / "run" / "weights"))
+    with contextlib.redirect_stdout(io.StringIO()):
+        G, D = model.Generator(**cfg), model.Discriminator(**cfg)
+        st = {"itr": 0, "epoch": 0, "save_num": 0, "save_best_num": 0, "best_IS": 0, "best_FID": 0}
+        utils.load_weights(G, D, st, cfg, weight_name=None, G_ema=None, load_optim=True)
+    assert st["itr"] == 7 and st["epoch"] == 1 and st["best_FID"] == 999999
+    n = 0
+    for net, name in ((G, "G"), (D, "D")):
+        for k, v in net.state_dict().items():
+            ref = sums[f"{name}.{k}"]
+            got = np.array([v.double().sum().item(), v.double().abs().sum().item()])
+            assert np.allclose(got, ref, rtol=1e-12, atol=1e-12), (name, k, got, ref)
+            n += 1
+    assert n == len(sums.files) - 1           # same key set as the reference's modules (no extra / missing entries)
+    raw = torch.load(tmp_path / "out" / "run" / "weights" / "G.pth", map_location="cpu")
+    assert all(torch.equal(raw[k], v) for k, v in G.state_dict().items())
 
 
 _STUBS = {"torchvision/__init__.py": "from . import transforms, datasets, utils\n",

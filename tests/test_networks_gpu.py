@@ -70,7 +70,7 @@ def test_train_step_256x768_subevent_vs_oracle():
     """The benchmark geometry (256x768, ch = 32: the persistent C = 16 / 32 halo kernels, LDS-resident-weight C = 64
     kernels, the split-K weight-gradient kernels, prologue_bwd / effgrad at 7.8 M pixels) on the first 8 sensors of an
     event, full train step against the fp32 oracle: losses, flat gradients, and the post-step state."""
-    rep = step_parity(256, 3, n=8, state_check=True)
+    rep = step_parity(256, 3, n=8, state_check=True, oracle_bf16=True)
     print(json.dumps(rep))
     assert rep["ok"], rep
     st = rep["state"]
@@ -78,6 +78,28 @@ def test_train_step_256x768_subevent_vs_oracle():
     assert st["G_sv0_rel_max"] <= 1e-3 and st["D_sv0_rel_max"] <= 1e-3, st
     assert st["G_bn_running_rel_max"] <= 5e-2, st
     assert st["G_param_rel"] <= 1e-3 and st["D_param_rel"] <= 1e-3, st             # one Adam step moves a weight by <= lr
+    assert st["D_update_sign_agree"] >= 0.9 and st["G_update_sign_agree"] >= 0.85, st
+    # The flat-gradient deviation at THIS geometry against its own rounding-noise floor: the fp32 oracle with its conv operands /
+    # outputs rounded to bf16 (O.ROUND_BF16) moves its own gradients by `fl`; the HIP path may be no further than 2x that.
+    fl = rep["bf16_floor"]
+    assert fl["G_grad_rel"] >= 1e-2, fl
+    assert rep["G_grad_rel"] <= 2.0 * fl["G_grad_rel"] + 1e-2, (rep["G_grad_rel"], fl)
+    assert rep["D_grad_rel"] <= 2.0 * fl["D_grad_rel"] + 1e-2, (rep["D_grad_rel"], fl)
+
+
+def test_train_step_256x768_full_event_vs_oracle():
+    """ALL 40 sensors at 256x768 -- the benchmark's exact launch geometry: the size-dependent launcher decisions (two-stage
+    weight-gradient accumulation above 8 MB of atomics, the >= 1024-tile wave-specialised 3x3 kernel, persistent-block tile
+    counts, the streaming 1x1 kernels' group counts) differ from the 8-sensor sub-event.  Losses, flat gradients and the
+    post-step state against the fp32 oracle (about a minute of host time, ~30 GB of host memory)."""
+    rep = step_parity(256, 3, n=40, state_check=True)
+    print(json.dumps(rep))
+    assert rep["ok"], rep
+    st = rep["state"]
+    assert st["G_u0_rel_max"] <= 2e-2 and st["D_u0_rel_max"] <= 2e-2, st
+    assert st["G_sv0_rel_max"] <= 1e-3 and st["D_sv0_rel_max"] <= 1e-3, st
+    assert st["G_bn_running_rel_max"] <= 5e-2, st
+    assert st["G_param_rel"] <= 1e-3 and st["D_param_rel"] <= 1e-3, st
     assert st["D_update_sign_agree"] >= 0.9 and st["G_update_sign_agree"] >= 0.85, st
 
 
@@ -103,6 +125,27 @@ def test_train_step_events_con_reg_vs_oracle_and_fixture(golden_dir):
     one = step_parity(64, 1, events=1, inputs=([xs[0]], [noises[0]]), Con_reg=True)
     for k in one["losses"]:
         assert abs(same["losses"][k] - one["losses"][k]) <= 2e-3 * max(1.0, abs(one["losses"][k])), (k, same["losses"], one["losses"])
+
+
+@pytest.mark.parametrize("tag,over", [("joint", {"split_D": False}), ("proj", {"conditional_strategy": "Proj"})])
+def test_train_step_joint_pass_and_projection_head(golden_dir, tag, over):
+    """``split_D=False`` (ONE discriminator pass over cat[G_z, x]: 80 RRM tokens, model.py:1024-1068) and the projection head
+    (``conditional_strategy='Proj'``, model.py:939-944) at 40x64x64: a full train step on the draws of the reference-generated
+    fixtures (make_golden_r3.py) -- losses against the reference's values, gradients / post-step state against the oracle."""
+    from test_oracle_golden import _load, _step_noise
+    from parity_util import O
+    g = _load(golden_dir, f"step_64_{tag}.npz")
+    noise = _step_noise(g)
+    y_g = noise.pop("y_g", None)
+    rep = step_parity(64, 1, state_check=True, inputs=([O.synth_event(40, 64, 64, 303)], [noise]), y_g=y_g, **over)
+    print(json.dumps(rep))
+    assert rep["ok"], rep
+    for k, v in rep["losses"].items():
+        ref = float(g["loss_" + k])
+        assert abs(v - ref) <= TOL["loss"] * max(1.0, abs(ref)), (k, v, ref)
+    st = rep["state"]
+    assert st["G_u0_rel_max"] <= 2e-2 and st["D_u0_rel_max"] <= 2e-2 and st["G_bn_running_rel_max"] <= 5e-2, st
+    assert st["G_param_rel"] <= 1e-3 and st["D_param_rel"] <= 1e-3, st
 
 
 def test_fp8_conv_path_forward_and_step_tolerance():
@@ -364,6 +407,24 @@ def test_train_entry_point_and_checkpoint_round_trip(tmp_path):
     assert torch.allclose(G._arena.flat[:G._arena.n_param], ref_opt.param_groups[0]["params"][0].data, rtol=1e-5, atol=1e-7)
 
 
+def test_train_entry_point_groups_events_per_step(tmp_path):
+    """train.py with ``--events_per_step 2`` on 5 synthetic events: every step consumes TWO events (x holds 80 images, y the
+    label vector twice, z_ 80 rows), the odd fifth event is dropped, and the metrics stay finite (a single event per step used
+    to reach the E = 2 train function: empty per-event slices, NaN losses)."""
+    import io, contextlib
+    import train
+    cfg = train.parse(["--synthetic", "5", "--resolution", "64", "--H_base", "1", "--clip_norm", "1e9", "--num_epochs", "1",
+                       "--events_per_step", "2", "--outputroot", str(tmp_path), "--shuffle", "false"])
+    with contextlib.redirect_stdout(io.StringIO()):
+        state = train.run(cfg)
+    assert state["itr"] == 2 and state["epoch"] == 1
+    lines = open(os.path.join(str(tmp_path), cfg["run_name"], "logs", "metrics_rank0.jsonl")).read().strip().splitlines()
+    assert len(lines) == 2
+    for ln in lines:
+        rec = json.loads(ln)
+        assert all(np.isfinite(v) for v in rec.values()), rec
+
+
 @pytest.mark.parametrize("graph", [False, True])
 def test_data_parallel_path_single_rank_rehearsal(graph):
     """The data-parallel code path (side-stream all-reduce + Adam, pre-forward waits, segmented HIP graphs) with a
@@ -388,7 +449,10 @@ def test_wgrad_side_stream_and_two_stage_accumulation_do_not_change_the_step():
     the step's D-phase / G-phase gradients after ``train`` returns."""
     import model, ops, train_fns, utils
     from parity_util import O, build_product, make_cfg, make_noise, rel_l2
-    cfg = make_cfg(resolution=256, H_base=3, clip_norm=1e9, hip_graph=False, ema=False, batch_size=8)
+    # D_lr = 0: D's Adam step leaves its weights where they were, so the G phase of every run sees the SAME discriminator and G's
+    # gradient is reproducible to rounding noise as well (with D moving, the last-bit differences of the D-phase gradient are
+    # amplified through Adam's g / sqrt(v) into percent-level changes of G's gradient, which hid the comparison below)
+    cfg = make_cfg(resolution=256, H_base=3, clip_norm=1e9, hip_graph=False, ema=False, batch_size=8, D_lr=0.0)
     x, y = O.synth_event(8, 256, 768, 404).cuda(), torch.arange(8).cuda()
     noise = make_noise(8, 256, 768, 919)            # explicit draws: both runs consume identical numbers
     results = []
@@ -414,6 +478,7 @@ def test_wgrad_side_stream_and_two_stage_accumulation_do_not_change_the_step():
     assert float(ga.norm()) > 0 and float(da.norm()) > 0
     assert noise_d < 1e-2, noise_d                                  # the D-phase gradient is reproducible to rounding noise
     assert diff_d <= max(4.0 * noise_d, 5e-3), (diff_d, noise_d)    # ... and the stream / accumulation form does not move it further
-    assert diff_g <= max(4.0 * noise_g, 0.35), (diff_g, noise_g)    # (measured: noise 1.3e-3 / 6.6e-2, difference 1.0e-3 / 1.6e-1)
+    assert noise_g < 2e-2, noise_g                                  # ... and so is the G-phase gradient once D stands still
+    assert diff_g <= max(4.0 * noise_g, 5e-3) and diff_g < 2e-2, (diff_g, noise_g)
     for k in oa:
         assert abs(oa[k] - ob[k]) <= 2e-2 * max(1.0, abs(oa[k])), (k, oa[k], ob[k])

@@ -296,6 +296,45 @@ def test_train_step_64(golden_dir, ref_cfg, tag, clip, moved):
     assert n_moved == moved == int(g["G_params_moved"])
 
 
+def _step_noise(g):
+    noise = {}
+    for ph in "dg":
+        noise["z_" + ph] = g["noise_z_" + ph]
+        noise["rdof_" + ph] = g["noise_rdof_" + ph]
+        noise["aug_" + ph] = {k.split("_", 3)[3]: g[k] for k in g if k.startswith(f"noise_aug_{ph}_")}
+    if "noise_y_g" in g:
+        noise["y_g"] = g["noise_y_g"].long()
+    return noise
+
+
+@pytest.mark.parametrize("tag,over", [("joint", {"split_D": False}), ("proj", {"conditional_strategy": "Proj"})])
+def test_train_step_64_joint_pass_and_projection_head(golden_dir, ref_cfg, tag, over):
+    """``split_D=False`` (D evaluated once on cat[G_z, x]: model.py:1024-1068; fixture = the reference's own train()) and
+    ``conditional_strategy='Proj'`` (model.py:939-944; the reference's train() under try/except + a composition of its
+    G_D / hinge calls, tests/golden/make_golden_r3.py): losses, per-parameter gradient norms, post-step checksums."""
+    g = _load(golden_dir, f"step_64_{tag}.npz")
+    cfg = dict(ref_cfg, resolution=64, H_base=1, ema=False, clip_norm=1e9, **over)
+    g0, d0 = O.synth_nets(cfg, 101, 202)
+    gsd, gp = O.as_trainable(g0)
+    dsd, dp = O.as_trainable(d0)
+    ts = O.TrainState(gsd, dsd, gp, dp, cfg)
+    out = O.train_step(ts, O.synth_event(40, 64, 64, 303), torch.arange(40), _step_noise(g), itr=1)
+    for k, v in out.items():
+        ref = g["loss_" + k].item()
+        assert abs(v - ref) <= 2e-4 * max(1.0, abs(ref)), (k, v, ref)
+    g_grads, d_grads = ts.last_grads
+    _close(torch.tensor([g_grads[k].norm().item() for k in gp]), g["G_gradnorm"], tol=5e-4, what="G grad norms")
+    _close(torch.tensor([d_grads[k].norm().item() for k in dp]), g["D_gradnorm"], tol=5e-4, what="D grad norms")
+    for name, sd, spec in (("G", gsd, O.g_spec(cfg)), ("D", dsd, O.d_spec(cfg))):
+        sums = torch.tensor([sd[k].double().sum().item() for k in spec], dtype=torch.float64)
+        asums = torch.tensor([sd[k].double().abs().sum().item() for k in spec], dtype=torch.float64)
+        assert torch.allclose(sums, g[f"{name}_sum"], rtol=1e-4, atol=1e-3), name
+        assert torch.allclose(asums, g[f"{name}_abssum"], rtol=1e-4, atol=1e-3), name
+    if tag == "proj":       # RR_D / norm exist (RRM_embed) but the projection head never evaluates them
+        assert all(float(d_grads[k].abs().max()) == 0.0 for k in dp if k.startswith("RR_D.") or k.startswith("norm."))
+        assert torch.equal(dsd["RR_D.layers.0.linear_net.0.u0"], d0["RR_D.layers.0.linear_net.0.u0"])
+
+
 def test_ingest_and_frechet_against_reference_vectors(golden_dir):
     """Event ingestion chain and the Frechet distance (fixtures written by tests/golden/make_golden_io.py from the
     reference's fn_lognorm255 / UniformNoise / frechet_distance)."""
