@@ -42,12 +42,19 @@ class WgradDesc(C.Structure):
                 ("dw", vp), ("tiles_per_block", C.c_int), ("pad_rows", C.c_int), ("partials", vp), ("colsum", vp)]
 
 
+class Conv1x1BwdDesc(C.Structure):
+    _fields_ = [("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("Kpad", C.c_int),
+                ("Kpad2", C.c_int), ("src", SrcDesc), ("g", vp), ("Cg", C.c_int), ("y", vp), ("dstat", vp), ("n_per_event", C.c_int),
+                ("geff_out", vp), ("w_bwd", vp), ("lg", vp), ("lC", C.c_int), ("lCa", C.c_int), ("lmode", C.c_int), ("dx", vp),
+                ("out_mode", C.c_int), ("bn_acc", vp), ("dw", vp), ("partials", vp), ("colsum", vp)]
+
+
 class ProfRec(C.Structure):
     _fields_ = [("name", C.c_char * 96), ("launches", C.c_long), ("ms", C.c_double),
                 ("flops", C.c_double), ("bytes", C.c_double), ("bytes_min", C.c_double)]
 
 
-ABI_VERSION = 6            # include/ieagan_hip.h: IEAGAN_ABI_VERSION
+ABI_VERSION = 7            # include/ieagan_hip.h: IEAGAN_ABI_VERSION
 i, f, l = C.c_int, C.c_float, C.c_long
 _SIGS = {
     "ieagan_abi_version": [],
@@ -57,6 +64,9 @@ _SIGS = {
     "ieagan_conv_forward": [C.POINTER(ConvDesc), vp],
     "ieagan_conv_wgrad": [C.POINTER(WgradDesc), i, vp],
     "ieagan_conv_wgrad_workspace": [C.POINTER(WgradDesc), i],
+    "ieagan_conv1x1_bwd": [C.POINTER(Conv1x1BwdDesc), vp],
+    "ieagan_conv1x1_bwd_workspace": [C.POINTER(Conv1x1BwdDesc)],
+    "ieagan_conv1x1_bwd_supported": [i, i, i, i],
     "ieagan_effgrad": [vp, vp, vp, vp, vp, l, i, i, vp],
     "ieagan_prologue_bwd": [vp, vp, i, vp, vp, i, i, i, vp, vp, vp, i, i, i, i, vp, i, i, i, vp],
     "ieagan_bn_finalize_fwd": [vp, f, vp, vp, i, i, f, f, i, vp, vp, vp, vp, vp, i, i, i, vp],

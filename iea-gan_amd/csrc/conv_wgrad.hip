@@ -341,6 +341,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// second stage for other producers of partial slabs (conv1x1_bwd.hip)
+int wgrad_reduce_launch(const float* part, float* dw, int S, int Cout, int Kpad, int K, hipStream_t st) {
+    const int zc = S > 2 * RED_CHUNK ? (S + RED_CHUNK - 1) / RED_CHUNK : 1;
+    const int chunk = (S + zc - 1) / zc;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((K / 4 + 255) / 256, Cout, zc), dim3(256), 0, st, part, dw, S, chunk, Cout, Kpad, K);
+    CHECK_LAUNCH("wgrad_reduce");
+    return 0;
+}
+
 struct WgradPlan {
     int mt, gx, gy, gz, tpb, pad_rows;
     bool special;

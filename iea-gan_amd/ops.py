@@ -614,6 +614,119 @@ def _placeholder(like):
     return _PLACEHOLDERS[key]
 
 
+# The whole backward of a 1x1 convolution on a large map in ONE launch (csrc/conv1x1_bwd.hip): effgrad + dgrad + prologue backward +
+# wgrad + bias column sums, every operand tile read once.  False: the separate launches (tests compare the two).
+FUSE_1X1_BACKWARD = True
+FUSE_1X1_MIN_PIXELS = 1 << 16
+
+
+def _fused_1x1_eligible(ctx, dout, dstats):
+    """Can ``ConvFn.backward`` take the fused 1x1 backward for this node?  (shape instantiated, big map, both gradients wanted, a
+    shortcut-gradient link the kernel can add in place.)"""
+    if not FUSE_1X1_BACKWARD:
+        return False
+    taps, rs, relu, Ca, ra_rs, nstride, Hc, Wc = ctx.cfg
+    rec = ctx.rec
+    need = ctx.needs_input_grad
+    has_bias, has_aff, has_ra, has_rb = ctx.has
+    res_out, res_in = ctx.links
+    x = ctx.saved_tensors[0]
+    N = x.shape[0]
+    if taps != 1 or rs not in (0, 2) or not need[0] or not need[1] or Wc % 32 != 0 or N * Hc * Wc < FUSE_1X1_MIN_PIXELS:
+        return False
+    if not H.lib().ieagan_conv1x1_bwd_supported(rec.cin, rec.out, rs, int(has_aff)):
+        return False
+    if isinstance(res_in, SumLink) or (has_aff and (rs != 0 or ctx.events > 1 and nstride == 0)):
+        return False
+    if res_in is not None and res_in.ready:
+        if rs == 2 and not (res_out is None and not relu and not has_aff):
+            return False            # a pooled source takes a link only as conv_sc (plain da + add at the pooled resolution, re-deposited)
+        if rs == 0 and res_in.mode not in (0, 1, 2):
+            return False
+    elif rs == 2 and res_out is None and not relu and res_in is not None:
+        return False                # conv_sc whose link was not produced: leave the bookkeeping to the generic path
+    if rs == 2 and rec.cin != 16 and (relu or res_in is None or not res_in.ready):
+        return False                # dx at source resolution of a pooled source exists for Cin = 16 only
+    st = dout.stride()
+    ok_stride = dout.is_contiguous() or (st[3] == 1 and st[2] % 8 == 0 and st[2] >= rec.out and st[1] == Wc * st[2] and
+                                         st[0] == Hc * Wc * st[2] and dout.data_ptr() % 16 == 0)
+    return ok_stride
+
+
+def _conv1x1_backward_fused(ctx, dout, dstats):
+    x, weight, scale, shift, out = ctx.saved_tensors
+    rec = ctx.rec
+    taps, rs, relu, Ca, ra_rs, nstride, Hc, Wc = ctx.cfg
+    has_bias, has_aff, has_ra, has_rb = ctx.has
+    res_out, res_in = ctx.links
+    N, Hs, Ws, Cx = x.shape
+    Cout, Cin = rec.out, rec.cin
+    dev = x.device
+    need = ctx.needs_input_grad
+    g = dout
+    Cg = Cout if dout.is_contiguous() else dout.stride()[2]
+    eff = dstats is not None
+    # g_eff has other consumers than this layer's own gradients when the shortcut operands need it: the kernel then stores it
+    shortcut_needs_g = (has_ra and need[5]) or (has_rb and need[6])
+    geff = torch.empty(N, Hc, Wc, Cout, dtype=BF16, device=dev) if (eff and shortcut_needs_g) else None
+    dstat = dstats[:, 0].contiguous() if eff else None
+    colsum = sn_scratch(rec, "b", (STAT_REPL, Cout), dev) if (has_bias and need[2]) else None
+    dwp = sn_scratch(rec, "w", (Cout, rec.kpad), dev)
+    # ---- shortcut-gradient link into dx
+    lg = lC = lCa = lmode = None
+    if res_in is not None and res_in.ready:
+        lg, lC, lCa, lmode = res_in.take()
+    conv_sc = rs == 2 and lg is not None            # D block conv_sc: plain da at the pooled resolution + the identity part, re-deposited
+    out_mode = 1 if conv_sc else 0
+    if conv_sc:
+        lmode = 0                                   # the deposited gradient lives at the block OUTPUT (= pooled) resolution
+    dx = torch.empty((N, Hc, Wc, Cin) if out_mode == 1 else (N, Hs, Ws, Cin), dtype=BF16, device=dev)
+    acc = zeros((N, H.BNB_REPL, 2, Cin), dev) if has_aff else None
+    d = H.Conv1x1BwdDesc(N, Hc, Wc, Cin, Cout, rec.kpad, rec.kpad2, H.src_desc(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu),
+                         g.data_ptr(), Cg, H.ptr(out) if eff else None, H.ptr(dstat), N // ctx.events, H.ptr(geff), rec.w_bwd.data_ptr(),
+                         H.ptr(lg), lC or 0, lCa or 0, lmode or 0, dx.data_ptr(), out_mode, H.ptr(acc), dwp.data_ptr(), None, H.ptr(colsum))
+    ws_n = H.lib().ieagan_conv1x1_bwd_workspace(d)
+    if ws_n > 0:
+        ws = torch.empty(ws_n, dtype=torch.float32, device=dev)
+        d.partials = ws.data_ptr()
+    H.call("ieagan_conv1x1_bwd", d, H.stream())
+    # ---- residual operands (as the generic path, on g_eff)
+    gl = geff if eff else g
+    d_ra = d_rb = None
+    if has_ra and need[5]:
+        rshape = ctx.ra_shape
+        if res_out is not None:
+            res_out.deposit(gl, gl.stride()[2] if not gl.is_contiguous() else Cout, Ca, ra_rs)
+        elif ra_rs == 0:
+            if Ca == Cout and rshape[-1] == Cout:
+                d_ra = gl
+            else:
+                d_ra = torch.zeros(rshape, dtype=BF16, device=dev)
+                d_ra[..., :Ca] = gl[..., :Ca]
+        else:
+            d_ra = torch.empty(rshape, dtype=BF16, device=dev)
+            H.call("ieagan_res_bwd", gl.contiguous().data_ptr(), Cout, d_ra.data_ptr(), rshape[-1], Ca, ra_rs, N, rshape[1], rshape[2],
+                   H.stream())
+    if has_rb and need[6]:
+        d_rb = gl[..., Ca:]
+    dscale = dshift = None
+    if has_aff:
+        bn_link = getattr(scale, "_bn_link", None)
+        if bn_link is not None:
+            bn_link.acc = acc
+            dscale = dshift = _placeholder(scale)
+        else:                       # stand-alone use (tests): fold the replicated per-image accumulators here
+            sums = acc.sum(1)
+            dshift, dscale = sums[:, 0], sums[:, 1]
+            if nstride == 0:
+                dshift, dscale = dshift.sum(0), dscale.sum(0)
+    if conv_sc:
+        res_in.deposit(dx, Cin, Cin, 2)
+        dx = None
+    dW, dbias = sn_backward(dwp, weight, rec, colsum, ctx.bias_ref)
+    return dx, dW, dbias, dscale, dshift, d_ra, d_rb, None, None, None, None, None, None, None, None, None, None
+
+
 class ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, scale, shift, ra, rb, rec, taps, rs, relu, Ca, ra_rs, want_stats, res_out, res_in, events=1):
@@ -640,6 +753,8 @@ class ConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout, dstats):
+        if _fused_1x1_eligible(ctx, dout, dstats):
+            return _conv1x1_backward_fused(ctx, dout, dstats)
         x, weight, scale, shift, out = ctx.saved_tensors
         rec = ctx.rec
         taps, rs, relu, Ca, ra_rs, nstride, Hc, Wc = ctx.cfg

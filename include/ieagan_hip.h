@@ -19,7 +19,7 @@ extern "C" {
 #endif
 
 const char* ieagan_last_error(void);
-#define IEAGAN_ABI_VERSION 6        /* bumped whenever a struct layout or a signature in this header changes */
+#define IEAGAN_ABI_VERSION 7        /* bumped whenever a struct layout or a signature in this header changes */
 int ieagan_abi_version(void);        /* == IEAGAN_ABI_VERSION of the header the library was built from */
 
 /* ---- profiling hooks (bench.py): per-kernel HIP-event timing on the launch stream ---- */
@@ -105,6 +105,42 @@ typedef struct {
 int ieagan_conv_wgrad(const ieagan_wgrad_desc* d, int use_tr_read, void* stream);
 /* floats of `partials` workspace the launch can use (0: the direct atomic accumulation is the better choice) */
 long ieagan_conv_wgrad_workspace(const ieagan_wgrad_desc* d, int use_tr_read);
+
+/* ---- the whole backward of a 1x1 convolution on a large feature map in one launch (conv1x1_bwd.hip) -------------------
+ * Replaces, per layer and backward pass, the launches ieagan_effgrad -> ieagan_conv_forward (as dgrad) [-> ieagan_prologue_bwd]
+ * -> ieagan_conv_wgrad, i.e. autograd of  F.conv2d(relu(bn(x)) | avg_pool(relu(x)), W / sigma, b)  for kernel_size 1 (reference
+ * layers.py:197-206, 656-689; model.py:54-71, 541-557): every operand tile is read once.
+ *   g_eff = g + dsum[e][c] + 2 y dsumsq[e][c]               (y / dstat NULL: g_eff = g; geff_out: g_eff is also stored, bf16 [N,H,W,Cout])
+ *   da    = g_eff W            (conv resolution)             w_bwd = the transposed pack [Cin][Kpad2], k = cout
+ *   out_mode 0:  dx[N,Hs,Ws,Cin] = prologue'(x) (.) resample^T(da) + shortcut gradient;  with the affine prologue dx = d * scale[n,c] and
+ *                bn_acc[N][8][2][Cin] += {sum d, sum d*x} per image (d = ReLU-masked da), as ieagan_conv_desc.bnb_*
+ *   out_mode 1:  dx[N,H,W,Cin]   = da + shortcut gradient   (plain prologue only; the pooled conv_sc of a D block, whose consumer expands)
+ *   dw[Cout][Kpad] += g_eff^T a,  a = the forward's A operand (prologue + 2x2 average pool applied);  colsum[32][Cout] += column sums of g_eff
+ * Shortcut gradient lg: channels [0, lCa) of a tensor with lC channels; lmode 0 same resolution as dx, 1 = 2x2 SUM of a tensor at double
+ * resolution, 2 = 0.25 * nearest expand of a tensor at half resolution.  Supported shapes: ieagan_conv1x1_bwd_supported; W % 32 == 0. */
+typedef struct {
+    int N, H, W;              /* conv (output) resolution                                                            */
+    int Cin, Cout, Kpad, Kpad2;
+    ieagan_src_desc src;      /* the forward's source operand with its prologue (rs 0 or 2)                          */
+    const void* g;            /* bf16 out-grad, channels [0,Cout) of Cg                                              */
+    int Cg;
+    const void* y;            /* bf16 [N,H,W,Cout] forward output (effgrad) or NULL                                  */
+    const float* dstat;       /* fp32 [E][2][Cout] (dsum, dsumsq) or NULL                                            */
+    int n_per_event;          /* images per event (0: one event)                                                     */
+    void* geff_out;           /* optional bf16 [N,H,W,Cout]                                                          */
+    const void* w_bwd;        /* bf16 [Cin][Kpad2]                                                                   */
+    const void* lg;           /* shortcut gradient or NULL                                                           */
+    int lC, lCa, lmode;
+    void* dx;                 /* bf16, see out_mode; NULL: no data gradient                                          */
+    int out_mode;
+    float* bn_acc;            /* fp32 [N][8][2][Cin], caller-zeroed (affine prologue)                                */
+    float* dw;                /* fp32 [Cout][Kpad], accumulated; NULL: no weight gradient                            */
+    float* partials;          /* optional workspace of ieagan_conv1x1_bwd_workspace(d) floats (two-stage accumulation) */
+    float* colsum;            /* optional fp32 [32][Cout] caller-zeroed replicas (bias gradient)                     */
+} ieagan_conv1x1_bwd_desc;
+int ieagan_conv1x1_bwd(const ieagan_conv1x1_bwd_desc* d, void* stream);
+long ieagan_conv1x1_bwd_workspace(const ieagan_conv1x1_bwd_desc* d);
+int ieagan_conv1x1_bwd_supported(int Cin, int Cout, int rs, int affine);
 
 /* ---- element-wise companions (bn_elem.hip) ---------------------------------------------------- */
 /* g_eff = dout + dsum[e][c] + 2*out*dsumsq[e][c]; colsum[32][C] += column sums (bias gradient).

@@ -800,3 +800,76 @@ def test_split_k_gather_matches_plain_gather(dev, taps, Cin, Cout, Hh, Ww, N, ev
         res.append((out, st.sum(1)))
     close(res[0][0], res[1][0], 4e-3, "split-K vs plain gather out")          # fp32 partial sums added in a different order
     close(res[0][1], res[1][1], 2e-3, "split-K vs plain gather statistics")
+
+
+@pytest.mark.parametrize("kind,cin,cout,flag,Hh,Ww,N", [
+    ("g", 64, 32, True, 32, 64, 3),       # G b11: conv1 64->16 (ccbn prologue, effgrad, 2x2-sum shortcut gradient), conv4 16->32 (g_eff stored for the link)
+    ("g", 64, 64, False, 32, 64, 3),      # G b10: same-resolution shortcut gradient, conv4 16->64
+    ("g", 128, 64, True, 16, 32, 2),      # G b9: conv4 32->64 fused, conv1 128->32 stays on the separate launches
+    ("d", 32, 64, True, 64, 64, 3),       # D s0.0: conv1 32->16 (+ 0.25 x expand of the pooled shortcut gradient), conv4 16->64 on the pooled source, conv_sc 32->32
+    ("d0", 32, 64, True, 64, 64, 3),      # ... as the very first block (no pre-activation)
+    ("d", 64, 64, False, 32, 64, 3),      # D s0.1: conv1 64->16, conv4 16->64, identity shortcut
+    ("d", 64, 128, True, 64, 64, 2),      # D s1.0: conv1 64->32 fused; conv4 32->128 / conv_sc 64->64 stay on the separate launches
+])
+def test_fused_1x1_backward_matches_separate_launches(dev, ref_cfg, kind, cin, cout, flag, Hh, Ww, N):
+    """ieagan_conv1x1_bwd (effgrad + dgrad + prologue backward + wgrad + bias sums in one launch, shortcut gradients added in the
+    kernel) against the separate launches on whole G / D blocks: output gradient, conditioning gradient and every parameter gradient
+    (incl. the spectral-norm sigma term).  The separate launches themselves are checked against fp32 PyTorch and the reference
+    vectors (test_conv_forward_backward, test_gblock_vs_golden, test_dblock_vs_golden)."""
+    import functools
+    import layers, model, ops
+    from parity_util import O
+    torch.manual_seed(3)
+
+    def build():
+        if kind == "g":
+            lin = functools.partial(layers.SNLinear, bias=False, eps=ref_cfg["SN_eps"])
+            blk = model.GBlock(cin, cout, functools.partial(layers.SNConv2d, kernel_size=3, padding=1, eps=ref_cfg["SN_eps"]),
+                               functools.partial(layers.ccbn, which_linear=lin, input_size=256, eps=ref_cfg["BN_eps"]),
+                               torch.nn.ReLU(inplace=True), functools.partial(F.interpolate, scale_factor=2) if flag else None)
+        else:
+            blk = model.DBlock(cin, cout, functools.partial(layers.SNConv2d, kernel_size=3, padding=1, eps=ref_cfg["SN_eps"]), True,
+                               kind == "d", torch.nn.ReLU(inplace=True), torch.nn.AvgPool2d(2) if flag else None)
+        spec = {k: tuple(v.shape) for k, v in blk.state_dict().items()}
+        blk.load_state_dict(O.synth_state(spec, 15))
+        return blk.to(dev).train()
+
+    x0 = torch.randn(N, cin, Hh, Ww, device=dev)
+    yv0 = torch.randn(N, 256, device=dev)
+    go = None
+    res = {}
+    keep = ops.FUSE_1X1_BACKWARD, ops.FUSE_1X1_MIN_PIXELS
+    launches = {}
+    try:
+        for fused in (False, True):
+            ops.FUSE_1X1_BACKWARD, ops.FUSE_1X1_MIN_PIXELS = fused, 1024
+            blk = build()
+            x = x0.clone().requires_grad_(True)
+            yv = yv0.clone().requires_grad_(True)
+            import _hip
+            _hip.call("ieagan_prof_reset")
+            _hip.prof_enable(1)
+            y = blk(x, yv) if kind == "g" else blk(x)
+            if go is None:
+                go = torch.randn_like(y)
+            params = dict(blk.named_parameters())
+            names = sorted(params)
+            leaves = [x] + ([yv] if kind == "g" else []) + [params[k] for k in names]
+            grads = torch.autograd.grad(y, leaves, go)
+            torch.cuda.synchronize()
+            _hip.prof_enable(0)
+            launches[fused] = {r["name"]: r["launches"] for r in _hip.prof_collect()}
+            res[fused] = (y.detach(), dict(zip(["x"] + (["yv"] if kind == "g" else []) + names, grads)))
+    finally:
+        ops.FUSE_1X1_BACKWARD, ops.FUSE_1X1_MIN_PIXELS = keep
+    assert launches[True].get("conv1x1_bwd", 0) >= 1 and "conv1x1_bwd" not in launches[False], launches
+    assert launches[True].get("conv1x1_wgrad", 0) < launches[False].get("conv1x1_wgrad", 0), launches
+    assert torch.equal(res[True][0], res[False][0])
+    wnorm = max(float(v.norm()) for k, v in res[False][1].items() if k not in ("x", "yv"))
+    for k, ref in res[False][1].items():
+        got = res[True][1][k]
+        if float(ref.norm()) < 2e-3 * wnorm:          # (a bias in front of a BatchNorm: zero up to rounding)
+            assert float(got.norm()) < 4e-3 * wnorm, k
+            continue
+        err = float((got - ref).norm() / ref.norm())
+        assert err <= 1e-2, (k, err)

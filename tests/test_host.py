@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, sym), f"{sym} declared in include/ieagan_hip.h but not exported"
     assert set(_hip.EXPORTS) <= declared
     lib.ieagan_abi_version.restype = ctypes.c_int
-    assert lib.ieagan_abi_version() == int(re.search(r"#define IEAGAN_ABI_VERSION (\d+)", header).group(1)) == 6
+    assert lib.ieagan_abi_version() == int(re.search(r"#define IEAGAN_ABI_VERSION (\d+)", header).group(1)) == _hip.ABI_VERSION
 
 
 def test_product_modules_match_reference_state_dict_contract(golden_dir, ref_cfg):

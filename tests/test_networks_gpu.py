@@ -441,44 +441,56 @@ def test_data_parallel_path_single_rank_rehearsal(graph):
     assert rec["n_gpus"] == 1 and rec["value"] > 0 and all(np.isfinite(v) for v in rec["losses_last_step"].values()), rec
 
 
-def test_wgrad_side_stream_and_two_stage_accumulation_do_not_change_the_step():
-    """Weight-gradient launches on the side stream / two-stage accumulation (the defaults) against the plain form -- every launch
-    on one stream, float atomics -- on the same nets, event and noise: an ordering bug between the streams (a missing join or
-    record_stream) would show up as a different gradient.  At a map size (8 sensors at 256x768) where the large layers take the
-    two-stage path and several weight-gradient launches are in flight behind the dgrad chain; the flat gradient arenas still hold
-    the step's D-phase / G-phase gradients after ``train`` returns."""
+def test_wgrad_side_stream_two_stage_and_fused_1x1_backward_do_not_change_the_step():
+    """Weight-gradient launches on the side stream / two-stage accumulation / the fused 1x1 backward (the defaults) against the plain
+    form -- every launch on one stream, float atomics, separate effgrad / dgrad / wgrad launches -- on the same nets, event and
+    noise: an ordering bug between the streams (a missing join or record_stream) or a wrong term in the fused kernel would show up
+    as a different gradient.  At a map size (8 sensors at 256x768) where the large layers take the two-stage path, several
+    weight-gradient launches are in flight behind the dgrad chain and every instantiated shape of the fused kernel runs.
+
+    What can be asserted: D's gradient is reproducible to rounding noise (1e-3) and must not move further.  G's gradient is NOT
+    reproducible run to run at this geometry even with identical settings and a frozen D (measured 8e-2 ... 1.6e-1 of the flat
+    gradient, tools/noise_probe.py: the float-atomic order of the BatchNorm statistics perturbs bf16 roundings, and 48 BatchNorm
+    backward stages -- each a cancellation g + dsum + 2 y dsumsq on bf16-stored operands -- amplify that with depth: blocks 0 / 1
+    carry most of it, the layers next to the output ~1e-4).  So G is compared PER PARAMETER against that parameter's own
+    run-to-run noise: a corrupted weight gradient (partial sums read before a join) is an O(1) error in one layer."""
     import model, ops, train_fns, utils
     from parity_util import O, build_product, make_cfg, make_noise, rel_l2
-    # D_lr = 0: D's Adam step leaves its weights where they were, so the G phase of every run sees the SAME discriminator and G's
-    # gradient is reproducible to rounding noise as well (with D moving, the last-bit differences of the D-phase gradient are
-    # amplified through Adam's g / sqrt(v) into percent-level changes of G's gradient, which hid the comparison below)
+    # D_lr = 0: D's Adam step leaves its weights where they were, so the G phase of every run sees the SAME discriminator
     cfg = make_cfg(resolution=256, H_base=3, clip_norm=1e9, hip_graph=False, ema=False, batch_size=8, D_lr=0.0)
     x, y = O.synth_event(8, 256, 768, 404).cuda(), torch.arange(8).cuda()
-    noise = make_noise(8, 256, 768, 919)            # explicit draws: both runs consume identical numbers
+    noise = make_noise(8, 256, 768, 919)            # explicit draws: all runs consume identical numbers
     results = []
-    for side, two in ((False, False), (True, True), (True, True)):
+    for side, two, fused in ((False, False, False), (True, True, True), (True, True, True)):
         g_state, d_state = O.synth_nets(cfg, 111, 222)
         G, D = build_product(cfg, g_state, d_state, "cuda:0")
         z_, y_ = utils.prepare_z_y(8, G.dim_z, cfg["n_classes"], device="cuda:0")
         train = train_fns.GAN_training_function(G, D, model.G_D(G, D), z_, y_, None, {"itr": 1}, cfg, "cuda:0")
-        keep = ops.WGRAD_SIDE_STREAM, ops.TWO_STAGE_WGRAD
-        ops.WGRAD_SIDE_STREAM, ops.TWO_STAGE_WGRAD = side, two
+        keep = ops.WGRAD_SIDE_STREAM, ops.TWO_STAGE_WGRAD, ops.FUSE_1X1_BACKWARD
+        ops.WGRAD_SIDE_STREAM, ops.TWO_STAGE_WGRAD, ops.FUSE_1X1_BACKWARD = side, two, fused
         try:
             out = train(x, y, noise=noise)
             torch.cuda.synchronize()
         finally:
-            ops.WGRAD_SIDE_STREAM, ops.TWO_STAGE_WGRAD = keep
-        results.append((out, G._arena.grad.clone(), D._arena.grad.clone()))
-    # Run-to-run noise of the SAME setting first (float atomics of the BatchNorm statistics make G(z) differ in its last bf16 bit;
-    # G's own gradient additionally sees D's Adam step, which amplifies that): B vs C.  Then A (plain) vs B (defaults).
-    (oa, ga, da), (ob, gb, db), (oc, gc, dc) = results
-    noise_g, noise_d = rel_l2(gc, gb), rel_l2(dc, db)
-    diff_g, diff_d = rel_l2(gb, ga), rel_l2(db, da)
+            ops.WGRAD_SIDE_STREAM, ops.TWO_STAGE_WGRAD, ops.FUSE_1X1_BACKWARD = keep
+        results.append((out, {k: p.grad.detach().clone() for k, p in G.named_parameters()}, D._arena.grad.clone(), G._arena.grad.clone()))
+    (oa, pa, da, ga), (ob, pb, db, gb), (oc, pc, dc, gc) = results
+    noise_d, diff_d = rel_l2(dc, db), rel_l2(db, da)
+    noise_g, diff_g = rel_l2(gc, gb), rel_l2(gb, ga)
     print(json.dumps(dict(noise_g=noise_g, noise_d=noise_d, diff_g=diff_g, diff_d=diff_d)))
     assert float(ga.norm()) > 0 and float(da.norm()) > 0
     assert noise_d < 1e-2, noise_d                                  # the D-phase gradient is reproducible to rounding noise
-    assert diff_d <= max(4.0 * noise_d, 5e-3), (diff_d, noise_d)    # ... and the stream / accumulation form does not move it further
-    assert noise_g < 2e-2, noise_g                                  # ... and so is the G-phase gradient once D stands still
-    assert diff_g <= max(4.0 * noise_g, 5e-3) and diff_g < 2e-2, (diff_g, noise_g)
+    assert diff_d <= max(4.0 * noise_d, 5e-3), (diff_d, noise_d)    # ... and neither the stream / accumulation form nor the fused kernel moves it
+    assert diff_g <= max(3.0 * noise_g, 2e-2), (diff_g, noise_g)
+    gmax = max(float(v.norm()) for v in pa.values())
+    bad = []
+    for k in pa:
+        if float(pa[k].norm()) < 1e-3 * gmax:          # (biases in front of a BatchNorm and the like: zero up to noise)
+            continue
+        nk, dk = rel_l2(pc[k], pb[k]), rel_l2(pb[k], pa[k])
+        if dk > max(4.0 * nk, 2e-2):
+            bad.append((k, dk, nk))
+    assert not bad, bad
+    print(json.dumps({k: [round(rel_l2(pc[k], pb[k]), 5), round(rel_l2(pb[k], pa[k]), 5)] for k in pa if k.endswith("conv4.weight")}))
     for k in oa:
         assert abs(oa[k] - ob[k]) <= 2e-2 * max(1.0, abs(oa[k])), (k, oa[k], ob[k])
