@@ -204,9 +204,13 @@ def measure(cfg, args, rank, world, local, tag):
     y = torch.arange(40, device=dev).repeat(E)
     G.train(); D.train(); G_ema.train()
 
+    trace = []
+
     def step():
         state["itr"] += 1
-        return train(xs[state["itr"] % n_rot], y)
+        out = train(xs[state["itr"] % n_rot], y)
+        trace.append(out)
+        return out
 
     for _ in range(max(args.warmup, 3 if cfg["hip_graph"] else 0)):    # graph mode: 2 eager steps + capture
         step()
@@ -256,7 +260,11 @@ def measure(cfg, args, rank, world, local, tag):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     parallel.set_context(None)
-    return dict(dt=dt, steps=steps, out=out, recs=recs, prof_steps=prof_steps, eager_timing=eager_timing, h=h, w=w, E=E)
+    if args.trace_losses and rank == 0:
+        for i, o in enumerate(trace):
+            print(f"[{tag}] step {i}: " + "  ".join(f"{k} {v:.4f}" for k, v in o.items()), file=sys.stderr)
+    return dict(dt=dt, steps=steps, out=out, recs=recs, prof_steps=prof_steps, eager_timing=eager_timing, h=h, w=w, E=E,
+                timed_losses=trace[-steps:])
 
 
 def kernel_report(res, m, args):
@@ -290,16 +298,21 @@ def kernel_report(res, m, args):
         try:        # cross-check of the launchers' 8(d) byte accounting against the architecture calculator
             import arch_calc
             calc = arch_calc.step_family_gbytes()
-            got = {"conv1x1_fwd_dgrad": 0.0, "conv3x3_fwd_dgrad": 0.0, "conv1x1_wgrad": 0.0, "conv3x3_wgrad": 0.0}
+            got = {"conv1x1_fwd_dgrad": 0.0, "conv3x3_fwd_dgrad": 0.0, "conv1x1_wgrad": 0.0, "conv3x3_wgrad": 0.0, "conv1x1_bwd_fused": 0.0}
             for r in recs:
                 fam = r["name"].split(" ")[0]
                 key = {"conv1x1_gather": "conv1x1_fwd_dgrad", "conv3x3_halo": "conv3x3_fwd_dgrad", "conv3x3_gather": "conv3x3_fwd_dgrad",
-                       "conv1x1_wgrad": "conv1x1_wgrad", "conv3x3_wgrad": "conv3x3_wgrad"}.get(fam)
+                       "conv1x1_wgrad": "conv1x1_wgrad", "conv3x3_wgrad": "conv3x3_wgrad", "conv1x1_bwd": "conv1x1_bwd_fused"}.get(fam)
                 if key:
                     got[key] += (r.get("bytes_min") or r["bytes"]) / prof_steps / 1e9
-            res["arch_calc_check"] = {k: {"calculator_gbytes": calc[k], "measured_launches_gbytes": got[k]} for k in got}
+            res["arch_calc_check"] = {k: {"calculator_gbytes": calc[k], "measured_launches_gbytes": got[k]} for k in got if k in calc}
             for k in ("conv1x1_fwd_dgrad", "conv3x3_fwd_dgrad"):      # dgrad launches of resampled layers: both operands at the
                 res["arch_calc_check"][k]["calculator_gbytes_dgrad_as_launched"] = calc[k + "_as_launched"]      # layer's resolution
+            # the fused 1x1 backward launches carry the dgrad AND the wgrad bytes of their layers: the three 1x1 families together
+            # must reproduce the calculator's 1x1 forward + dgrad + wgrad total
+            res["arch_calc_check"]["conv1x1_all"] = {
+                "calculator_gbytes": calc["conv1x1_fwd_dgrad_as_launched"] + calc["conv1x1_wgrad"],
+                "measured_launches_gbytes": got["conv1x1_fwd_dgrad"] + got["conv1x1_wgrad"] + got["conv1x1_bwd_fused"]}
         except Exception as e:
             res["arch_calc_check"] = f"unavailable: {e}"
 
@@ -318,6 +331,8 @@ def main():
     ap.add_argument("--resolution", type=int, default=256)
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying a HIP graph")
     ap.add_argument("--shape-tags", action="store_true", help="per-kernel timing split by layer shape (tuning aid)")
+    ap.add_argument("--trace-losses", action="store_true", help="print the losses of every step to stderr (tuning aid)")
+    ap.add_argument("--lr", type=float, default=None, help="override G_lr / D_lr of the benchmark configuration (tuning aid)")
     args = ap.parse_args()
 
     import _hip
@@ -331,6 +346,8 @@ def main():
 
     def cfg_for(which):
         cfg = bench_config(which)
+        if args.lr is not None:
+            cfg.update(G_lr=args.lr, D_lr=args.lr)
         cfg["resolution"] = args.resolution
         cfg["hip_graph"] = not args.no_graph
         if args.resolution != 256:
@@ -353,8 +370,11 @@ def main():
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
            "config": {"workload": desc3 if args.only_configs3 else desc1, "events_per_gpu_per_step": E,
                       "parallelism": f"dp{world}", "clip_norm": cfg["clip_norm"], "hip_graph": bool(cfg["hip_graph"])},
+           "losses_last_step": m["out"], "roofline": None, "cpu_baseline": None,
            "step_tflops_algorithmic": STEP_GFLOP * 1e-3 * world * steps / dt if (args.resolution == 256 and E == 1) else None,
-           "losses_last_step": m["out"], "git_head": git_head()}
+           "git_head": git_head()}
+    sat = [o for o in m["timed_losses"] if not (o["D_loss_real"] > 0.0 and o["D_loss_fake"] > 0.0)]
+    res["hinge_unsaturated_in_every_timed_step"] = not sat          # both D hinge terms > 0: every backward pass carries non-zero gradients
     if m["recs"]:
         kernel_report(res, m, args)
     if world == 1 and not args.no_configs3 and not args.only_configs3:

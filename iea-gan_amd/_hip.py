@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libieagan_hip.so")
 CONV_FP8 = 4             # ieagan_conv_desc.flags bit: e4m3 MFMA operands in the forward C = 64 / 128 3x3 launches (configs[4])
 CONV_NO_LDS_WEIGHTS = 2  # ieagan_conv_desc.flags bit: C = 64 / 128 3x3 layers through conv3x3_halo instead of conv3x3_lds
 CONV_FORCE_GATHER = 1   # ieagan_conv_desc.flags bit (tests): route a 3x3 layer through the gather kernel
+B1_OCC2, B1_OCC3, B1_TP32 = 1, 2, 4  # ieagan_conv1x1_bwd_desc.flags bits (benchmarks)
 BNB_REPL = 8            # replicas of the per-image accumulators of a BatchNorm-backward dgrad launch (common.h)
 STAT_REPL = 32          # replicas of every (sum, sumsq) statistics buffer (common.h)
 SN_FIELDS = 16          # int64 fields per row of the spectral-norm layer table (sn.hip)
@@ -46,7 +47,7 @@ class Conv1x1BwdDesc(C.Structure):
     _fields_ = [("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("Kpad", C.c_int),
                 ("Kpad2", C.c_int), ("src", SrcDesc), ("g", vp), ("Cg", C.c_int), ("y", vp), ("dstat", vp), ("n_per_event", C.c_int),
                 ("geff_out", vp), ("w_bwd", vp), ("lg", vp), ("lC", C.c_int), ("lCa", C.c_int), ("lmode", C.c_int), ("dx", vp),
-                ("out_mode", C.c_int), ("bn_acc", vp), ("dw", vp), ("partials", vp), ("colsum", vp)]
+                ("out_mode", C.c_int), ("bn_acc", vp), ("dw", vp), ("partials", vp), ("colsum", vp), ("flags", C.c_int)]
 
 
 class ProfRec(C.Structure):

@@ -25,7 +25,6 @@
 
 typedef ieagan_conv1x1_bwd_desc Bwd1Args;
 
-#define B1_TP 32          // conv-resolution pixels per wave tile
 
 __host__ __device__ constexpr int b1_stride(int C) { return ((C / 16) % 2 == 0) ? C + 16 : C; }      // elements; odd multiple of 32 bytes
 
@@ -43,19 +42,21 @@ __device__ __forceinline__ bf16x8 b1_frag_T(const bf16* lds, int stride_elems, i
     return f;
 }
 
-template <int CIN, int COUT, int RS, bool AFF>
+// TP: conv-resolution pixels per wave tile (32 or 64).  64 keeps twice the bytes in flight per wave -- these launches wait on memory
+// (rocprofv3: 40-70 % of the wave cycles parked in s_waitcnt at two waves per SIMD) -- where the LDS tiles of two blocks still fit a CU.
+template <int CIN, int COUT, int RS, bool AFF, int TP>
 struct B1Cfg {
     static constexpr int GS = b1_stride(COUT), XS = b1_stride(CIN);
     static constexpr int CPG = COUT / 8, CPX = CIN / 8;           // 16-byte chunks per pixel
-    static constexpr int GCH = B1_TP * CPG / 64;                   // g chunks per lane and tile
-    static constexpr int XIT = B1_TP * CPX / 64;                   // x items per lane and tile (an item = one chunk; 2x2 chunks when pooled)
+    static constexpr int GCH = TP * CPG / 64;                   // g chunks per lane and tile
+    static constexpr int XIT = TP * CPX / 64;                   // x items per lane and tile (an item = one chunk; 2x2 chunks when pooled)
     static constexpr int KS_D = (COUT + 31) / 32, NT_D = CIN / 16; // dgrad: k-steps over cout, n-tiles over cin
     static constexpr int MT_W = COUT / 16, NJ_W = CIN / 16;        // wgrad: m-tiles over cout, n-tiles over cin
     static constexpr int EROWS = (CIN == 16) ? 32 : 16;            // pixel rows per epilogue pass (a pass must fill whole waves)
-    static constexpr int EPASS = B1_TP / EROWS;
+    static constexpr int EPASS = TP / EROWS;
     static constexpr int EIT = EROWS * CPX / 64;                   // items per lane and pass
     static constexpr int LDW = NT_D * 16 + 4;                      // padded fp32 transpose row
-    static constexpr int G_BYTES = B1_TP * GS * 2, X_BYTES = B1_TP * XS * 2, E_BYTES = EROWS * LDW * 4;
+    static constexpr int G_BYTES = TP * GS * 2, X_BYTES = TP * XS * 2, E_BYTES = EROWS * LDW * 4;
     static constexpr int WAVE_BYTES = G_BYTES + X_BYTES + E_BYTES;
     static constexpr int FOLD_BYTES = (COUT * CIN + COUT) * 4;     // block-end fold of the four partial dW (+ column sums)
     static constexpr int SX_BYTES = 4 * STATS_SX_FLOATS * 4;
@@ -65,12 +66,13 @@ struct B1Cfg {
     static_assert(64 % CPG == 0 && 64 % CPX == 0, "a lane's channel chunk must not change between its items");
 };
 
-template <int CIN, int COUT, int RS, bool AFF>
-__global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(Bwd1Args a, int tpi, int tpb, int bpi, int nblk) {
-    typedef B1Cfg<CIN, COUT, RS, AFF> K;
+template <int CIN, int COUT, int RS, bool AFF, int OCC, int TP>
+__global__ __launch_bounds__(256, OCC) void conv1x1_bwd_kernel(Bwd1Args a, int tpi, int tpb, int bpi, int nblk) {
+    typedef B1Cfg<CIN, COUT, RS, AFF, TP> K;
     __shared__ __attribute__((aligned(16))) char smem[K::SMEM];
     __shared__ float red[4 * K::NT_D * 16 * 2];
     __shared__ __attribute__((aligned(32))) float aff_s[AFF ? 2 * CIN : 8];
+    __shared__ __attribute__((aligned(32))) float eff_s[2 * COUT];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 15, lg = lane >> 4;
     const int H = a.H, W = a.W, HW = H * W;
@@ -98,8 +100,15 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(Bwd1Args a, int tpi
             aff_s[i] = a.src.scale[(long)n * a.src.aff_nstride + i];
             aff_s[CIN + i] = a.src.shift[(long)n * a.src.aff_nstride + i];
         }
-        __syncthreads();
     }
+    if (eff) {
+        const int ev = (a.n_per_event > 0) ? n / a.n_per_event : 0;
+        for (int i = threadIdx.x; i < COUT; i += 256) {
+            eff_s[i] = a.dstat[(long)ev * 2 * COUT + i];
+            eff_s[COUT + i] = 2.f * a.dstat[(long)ev * 2 * COUT + COUT + i];
+        }
+    }
+    __syncthreads();
     typedef const __attribute__((address_space(3))) float* lds_cf;
     bf16x8 bfrag[K::KS_D][K::NT_D];                               // B[k = cout][col = cin]: rows of the transposed pack [Cin][Kpad2]
 #pragma unroll
@@ -110,21 +119,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(Bwd1Args a, int tpi
             bfrag[ks][nt] = (k < COUT) ? *(const bf16x8*)((const bf16*)a.w_bwd + (long)(nt * 16 + lr) * a.Kpad2 + k) : zero8();
         }
     const int ccg = lane % K::CPG, ccx = lane % K::CPX;          // this lane's channel chunk in g / in x (fixed over its items)
-    float ds[8], dq[8];
-    {
-        const int ev = (a.n_per_event > 0) ? n / a.n_per_event : 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            ds[i] = eff ? a.dstat[(long)ev * 2 * COUT + ccg * 8 + i] : 0.f;
-            dq[i] = eff ? 2.f * a.dstat[(long)ev * 2 * COUT + COUT + ccg * 8 + i] : 0.f;
-        }
-    }
-    float sc8[8], sh8[8];                                         // BatchNorm rows of this lane's x chunk (epilogue)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        sc8[i] = AFF ? aff_s[ccx * 8 + i] : 1.f;
-        sh8[i] = AFF ? aff_s[CIN + ccx * 8 + i] : 0.f;
-    }
+    typedef const __attribute__((address_space(3))) f32x4* lds_cf4;
+    const float* dsl = eff_s + ccg * 8;                           // {dsum, 2 dsumsq} rows of this lane's g chunk (LDS)
     float s1[8], s2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
@@ -145,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(Bwd1Args a, int tpi
     // ---- raw operand requests of one tile (no transform)
     bf16x8 rg[K::GCH], ry[K::GCH], rx[K::XIT][RS == 2 ? 4 : 1];
     auto request = [&](int t) {
-        const long p0 = img_px + (long)t * B1_TP;
+        const long p0 = img_px + (long)t * TP;
 #pragma unroll
         for (int j = 0; j < K::GCH; ++j) {
             const int px = (j * 64 + lane) / K::CPG;
@@ -159,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(Bwd1Args a, int tpi
                 rx[j][0] = *(const bf16x8*)((const bf16*)a.src.x + (p0 + px) * a.src.Cx + ccx * 8);
             }
         } else {
-            const int tl = t * B1_TP;                             // W % 32 == 0: a tile lies inside one conv row
+            const int tl = t * TP;                             // W % 32 == 0: a tile lies inside one conv row
             const int h = tl / W, w0 = tl - h * W;
 #pragma unroll
             for (int j = 0; j < K::XIT; ++j) {
@@ -175,8 +171,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(Bwd1Args a, int tpi
 
     if (t0 + wave < t1) request(t0 + wave);
     for (int t = t0 + wave; t < t1; t += 4) {
-        const long p0 = img_px + (long)t * B1_TP;
-        const int tl = t * B1_TP;
+        const long p0 = img_px + (long)t * TP;
+        const int tl = t * TP;
         const int th = tl / W, tw0 = tl - th * W;                 // conv coordinates of the tile's first pixel
         // ---- 1. stage the tile (this wave's private LDS: in-order LDS operations, no block barrier)
         constexpr bool KEEPX = RS == 2 && CIN == 16;              // pooled source with dx at source resolution (launcher: only Cin = 16)
@@ -186,8 +182,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(Bwd1Args a, int tpi
             const int px = (j * 64 + lane) / K::CPG;
             bf16x8 wv = rg[j];
             if (eff) {
+                const f32x4 d0 = *(lds_cf4)(dsl), d1 = *(lds_cf4)(dsl + 4), q0 = *(lds_cf4)(dsl + COUT), q1 = *(lds_cf4)(dsl + COUT + 4);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) wv[i] = f2bf(bf2f(rg[j][i]) + ds[i] + bf2f(ry[j][i]) * dq[i]);
+                for (int i = 0; i < 8; ++i)
+                    wv[i] = f2bf(bf2f(rg[j][i]) + (i < 4 ? d0[i & 3] : d1[i & 3]) + bf2f(ry[j][i]) * (i < 4 ? q0[i & 3] : q1[i & 3]));
                 if (a.geff_out != nullptr) *(bf16x8*)((bf16*)a.geff_out + (p0 + px) * COUT + ccg * 8) = wv;
             }
             *(bf16x8*)(lds_g + px * K::GS + ccg * 8) = wv;
@@ -235,7 +233,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(Bwd1Args a, int tpi
         __builtin_amdgcn_wave_barrier();
         // ---- 3. weight gradient (+ bias column sums): one K step of 32 pixels
         if (want_w) {
-            const int pix0 = (lg >> 1) * 16 + (lg & 1) * 4;
+#pragma unroll
+          for (int kk = 0; kk < TP / 32; ++kk) {
+            const int pix0 = kk * 32 + (lg >> 1) * 16 + (lg & 1) * 4;
             bf16x8 afr[K::MT_W];
 #pragma unroll
             for (int mt = 0; mt < K::MT_W; ++mt) afr[mt] = b1_frag_T(lds_g, K::GS, pix0, mt * 16, lr);
@@ -261,6 +261,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(Bwd1Args a, int tpi
 #pragma unroll
                 for (int mt = 0; mt < K::MT_W; ++mt) accc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[mt], ones, accc[mt], 0, 0, 0);
             }
+          }
         }
         // ---- 4. data gradient, EROWS pixel rows per pass
         if (a.dx != nullptr) {
@@ -308,15 +309,23 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(Bwd1Args a, int tpi
                     }
                     if (a.out_mode == 0 && (AFF || relu)) {
                         const bf16x8 xv = *(const bf16x8*)(lds_x + px * K::XS + ccx * 8);        // RS == 0: the raw x tile is still in LDS
+                        f32x4 c0 = {1.f, 1.f, 1.f, 1.f}, c1 = c0, h0 = {0.f, 0.f, 0.f, 0.f}, h1 = h0;
+                        if (AFF) {
+                            c0 = *(lds_cf4)(aff_s + ccx * 8);
+                            c1 = *(lds_cf4)(aff_s + ccx * 8 + 4);
+                            h0 = *(lds_cf4)(aff_s + CIN + ccx * 8);
+                            h1 = *(lds_cf4)(aff_s + CIN + ccx * 8 + 4);
+                        }
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
                             const float xf = bf2f(xv[i]);
-                            const float pre = AFF ? xf * sc8[i] + sh8[i] : xf;
+                            const float sc = i < 4 ? c0[i & 3] : c1[i & 3], sh = i < 4 ? h0[i & 3] : h1[i & 3];
+                            const float pre = AFF ? xf * sc + sh : xf;
                             const float d = (relu && !(pre > 0.f)) ? 0.f : v[i];
                             if (AFF) {
                                 s1[i] += d;                       // -> d shift
                                 s2[i] += d * xf;                  // -> d scale
-                                v[i] = d * sc8[i];
+                                v[i] = d * sc;
                             } else {
                                 v[i] = d;
                             }
@@ -416,7 +425,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_bwd_kernel(Bwd1Args a, int tpi
 
 // ------------------------------------------------------------------------------------------------
 struct B1Plan {
-    int tpi, tpb, bpi, nblk;
+    int tpi, tpb, bpi, nblk, tp;
+    bool occ3;
     long ws_elems;
 };
 
@@ -427,11 +437,23 @@ static bool b1_shape_ok(int cin, int cout, int rs, bool aff) {
            (cin == 16 && cout == 32) || (cin == 32 && cout == 64) || (cin == 32 && cout == 32);
 }
 
+// blocks per CU (= waves per SIMD): three only where 168 registers hold the kernel without spills AND it measured faster
+// (measured at N = 40, tools/bwd1x1_bench.py: never faster than two blocks with 64-pixel tiles; kept for benchmarks, IEAGAN_B1_OCC3)
+static bool b1_occ3(int cin, int cout, int rs, bool aff) { return false; }
+// 64-pixel wave tiles where two blocks of four such waves still fit the 160 KB of a CU
+static int b1_tp(int cin, int cout, int rs) {
+    if (rs == 2) return cin == 32 ? 64 : 32;           // (Cin = 16 keeps the raw 2x2 chunks in registers: spills at 64)
+    return (cin * cout == 2048) ? 32 : 64;             // 64 <-> 32 channels: LDS (two blocks per CU) / registers
+}
+
 static int b1_plan(const Bwd1Args& a, B1Plan& p) {
     CHECK_ARG(a.src.rs == 0 || a.src.rs == 2, "conv1x1_bwd: resample mode %d", a.src.rs);
     CHECK_ARG(b1_shape_ok(a.Cin, a.Cout, a.src.rs, a.src.scale != nullptr), "conv1x1_bwd: shape %d -> %d (rs %d, affine %d) is not instantiated", a.Cin, a.Cout,
               a.src.rs, a.src.scale != nullptr);
-    CHECK_ARG(a.W % B1_TP == 0, "conv1x1_bwd: W %% 32 required (W = %d)", a.W);
+    const bool occ3 = (a.flags & IEAGAN_B1_OCC2) ? false : ((a.flags & IEAGAN_B1_OCC3) ? true : b1_occ3(a.Cin, a.Cout, a.src.rs, a.src.scale != nullptr));
+    int TP = (a.flags & IEAGAN_B1_TP32) || occ3 ? 32 : b1_tp(a.Cin, a.Cout, a.src.rs);
+    if (a.W % TP != 0) TP = 32;                       // a tile must lie inside one row
+    CHECK_ARG(a.W % TP == 0, "conv1x1_bwd: W %% 32 required (W = %d)", a.W);
     if (a.src.rs == 0) CHECK_ARG(a.H == a.src.Hs && a.W == a.src.Ws, "conv1x1_bwd: geometry mismatch");
     if (a.src.rs == 2) CHECK_ARG(2 * a.H == a.src.Hs && 2 * a.W == a.src.Ws, "conv1x1_bwd: pool geometry mismatch");
     CHECK_ARG(a.Kpad % 32 == 0 && a.Kpad >= a.Cin && a.Kpad2 % 32 == 0 && a.Kpad2 >= a.Cout, "conv1x1_bwd: bad weight-pack row lengths");
@@ -451,15 +473,20 @@ static int b1_plan(const Bwd1Args& a, B1Plan& p) {
         if (a.lmode == 2) CHECK_ARG(a.H % 2 == 0 && a.W % 2 == 0, "conv1x1_bwd: half-resolution shortcut gradient needs even H, W");
     }
     CHECK_ARG(a.dx != nullptr || a.dw != nullptr, "conv1x1_bwd: nothing to compute");
+    CHECK_ARG((a.flags & ~(IEAGAN_B1_OCC2 | IEAGAN_B1_OCC3 | IEAGAN_B1_TP32)) == 0, "conv1x1_bwd: unknown flag bits 0x%x", a.flags);
     CHECK_ARG(a.colsum == nullptr || a.dw != nullptr, "conv1x1_bwd: colsum rides on the weight gradient");
-    const int tpi = a.H * a.W / B1_TP;
-    // ~4 blocks per CU in total; whole blocks per image; 4 waves interleave the tiles of a block
-    int bpi = (1024 + a.N - 1) / a.N;
+    const int tpi = a.H * a.W / TP;
+    // ONE round of persistent blocks: every resident slot (256 CUs x blocks per CU) gets one block, whole blocks per image, the four
+    // waves of a block interleave its tiles.  (A grid of 1040 blocks on 512 slots ran three rounds, the last one 3 % full.)
+    const int slots = 256 * (occ3 ? 3 : 2);
+    int bpi = slots / a.N;
     if (bpi < 1) bpi = 1;
     int tpb = (tpi + bpi - 1) / bpi;
     tpb = (tpb + 3) / 4 * 4;
     if (tpb < 8) tpb = 8;
     bpi = (tpi + tpb - 1) / tpb;
+    p.tp = TP;
+    p.occ3 = occ3;
     p.tpi = tpi;
     p.tpb = tpb;
     p.bpi = bpi;
@@ -490,7 +517,9 @@ extern "C" int ieagan_conv1x1_bwd(const ieagan_conv1x1_bwd_desc* d, void* stream
     const double P = (double)a.N * a.H * a.W, Ps = (double)a.N * a.src.Hs * a.src.Ws;
     const double flops = 2.0 * P * (double)a.Cout * a.Cin * ((a.dx ? 1 : 0) + (a.dw ? 1 : 0));
     // algorithmic bytes (layer-granular): dgrad R g + W dx, wgrad R x + R g -- what the replaced launches were charged
-    const double bytes_min = 2.0 * ((a.dx ? P * a.Cout + Ps * a.Cin : 0.0) + (a.dw ? Ps * a.Cin + P * a.Cout : 0.0));
+    // (the dgrad of a pooled layer is charged at the layer's own resolution, as tools/arch_calc.py's "as launched" figures do: the fold
+    //  back to the source resolution used to be prologue_bwd's traffic)
+    const double bytes_min = 2.0 * ((a.dx ? P * a.Cout + P * a.Cin : 0.0) + (a.dw ? Ps * a.Cin + P * a.Cout : 0.0));
     double bytes = 2.0 * (P * a.Cout + Ps * a.Cin + (a.dx ? (a.out_mode == 0 ? Ps : P) * a.Cin : 0.0));        // what this launch moves
     if (a.y) bytes += 2.0 * P * a.Cout * (a.geff_out ? 2 : 1);
     if (a.lg) bytes += 2.0 * P * a.lCa * (a.lmode == 1 ? 4.0 : (a.lmode == 2 ? 0.25 : 1.0));
@@ -499,16 +528,21 @@ extern "C" int ieagan_conv1x1_bwd(const ieagan_conv1x1_bwd_desc* d, void* stream
         snprintf(tag, sizeof(tag), "ci%d co%d %dx%d rs%d a%d r%d eff%d l%d w%d", a.Cin, a.Cout, a.H, a.W, a.src.rs, a.src.scale != nullptr, a.src.relu,
                  a.y != nullptr, a.lg ? a.lmode : -1, a.dw != nullptr);
     ProfScope prof("conv1x1_bwd", flops, bytes, st, tag, bytes_min);
-#define B1_LAUNCH(CI, CO, RSV, AF) \
-    hipLaunchKernelGGL((conv1x1_bwd_kernel<CI, CO, RSV, AF>), dim3(p.nblk), dim3(256), 0, st, a, p.tpi, p.tpb, p.bpi, p.nblk)
+    const bool occ3 = p.occ3;
+#define B1_LAUNCH(CI, CO, RSV, AF)                                                                                                   \
+    {                                                                                                                                \
+        if (occ3) hipLaunchKernelGGL((conv1x1_bwd_kernel<CI, CO, RSV, AF, 3, 32>), dim3(p.nblk), dim3(256), 0, st, a, p.tpi, p.tpb, p.bpi, p.nblk); \
+        else if (p.tp == 32) hipLaunchKernelGGL((conv1x1_bwd_kernel<CI, CO, RSV, AF, 2, 32>), dim3(p.nblk), dim3(256), 0, st, a, p.tpi, p.tpb, p.bpi, p.nblk); \
+        else hipLaunchKernelGGL((conv1x1_bwd_kernel<CI, CO, RSV, AF, 2, 64>), dim3(p.nblk), dim3(256), 0, st, a, p.tpi, p.tpb, p.bpi, p.nblk);      \
+    }
 #define B1_CASE(CI, CO)                                                      \
     if (a.Cin == CI && a.Cout == CO) {                                       \
-        if (a.src.scale != nullptr) B1_LAUNCH(CI, CO, 0, true);              \
-        else B1_LAUNCH(CI, CO, 0, false);                                    \
+        if (a.src.scale != nullptr) B1_LAUNCH(CI, CO, 0, true)               \
+        else B1_LAUNCH(CI, CO, 0, false)                                     \
     } else
     if (a.src.rs == 2) {
-        if (a.Cin == 16 && a.Cout == 64) B1_LAUNCH(16, 64, 2, false);
-        else B1_LAUNCH(32, 32, 2, false);
+        if (a.Cin == 16 && a.Cout == 64) B1_LAUNCH(16, 64, 2, false)
+        else B1_LAUNCH(32, 32, 2, false)
     } else {
         B1_CASE(32, 16) B1_CASE(64, 16) B1_CASE(64, 32) B1_CASE(16, 64) B1_CASE(16, 32) B1_CASE(32, 64) B1_CASE(32, 32) {}
     }

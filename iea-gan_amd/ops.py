@@ -618,6 +618,7 @@ def _placeholder(like):
 # wgrad + bias column sums, every operand tile read once.  False: the separate launches (tests compare the two).
 FUSE_1X1_BACKWARD = True
 FUSE_1X1_MIN_PIXELS = 1 << 16
+FUSE_1X1_FLAGS = 0              # benchmarks only: H.B1_OCC2 / H.B1_OCC3
 
 
 def _fused_1x1_eligible(ctx, dout, dstats):
@@ -684,7 +685,8 @@ def _conv1x1_backward_fused(ctx, dout, dstats):
     acc = zeros((N, H.BNB_REPL, 2, Cin), dev) if has_aff else None
     d = H.Conv1x1BwdDesc(N, Hc, Wc, Cin, Cout, rec.kpad, rec.kpad2, H.src_desc(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu),
                          g.data_ptr(), Cg, H.ptr(out) if eff else None, H.ptr(dstat), N // ctx.events, H.ptr(geff), rec.w_bwd.data_ptr(),
-                         H.ptr(lg), lC or 0, lCa or 0, lmode or 0, dx.data_ptr(), out_mode, H.ptr(acc), dwp.data_ptr(), None, H.ptr(colsum))
+                         H.ptr(lg), lC or 0, lCa or 0, lmode or 0, dx.data_ptr(), out_mode, H.ptr(acc), dwp.data_ptr(), None, H.ptr(colsum),
+                         FUSE_1X1_FLAGS)
     ws_n = H.lib().ieagan_conv1x1_bwd_workspace(d)
     if ws_n > 0:
         ws = torch.empty(ws_n, dtype=torch.float32, device=dev)

@@ -137,7 +137,11 @@ typedef struct {
     float* dw;                /* fp32 [Cout][Kpad], accumulated; NULL: no weight gradient                            */
     float* partials;          /* optional workspace of ieagan_conv1x1_bwd_workspace(d) floats (two-stage accumulation) */
     float* colsum;            /* optional fp32 [32][Cout] caller-zeroed replicas (bias gradient)                     */
+    int flags;                /* IEAGAN_B1_* (benchmarks: force the 2 / 3 blocks-per-CU build of the kernel)         */
 } ieagan_conv1x1_bwd_desc;
+#define IEAGAN_B1_OCC2 1
+#define IEAGAN_B1_OCC3 2
+#define IEAGAN_B1_TP32 4          /* 32-pixel wave tiles everywhere */
 int ieagan_conv1x1_bwd(const ieagan_conv1x1_bwd_desc* d, void* stream);
 long ieagan_conv1x1_bwd_workspace(const ieagan_conv1x1_bwd_desc* d);
 int ieagan_conv1x1_bwd_supported(int Cin, int Cout, int rs, int affine);

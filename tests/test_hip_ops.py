@@ -864,7 +864,8 @@ def test_fused_1x1_backward_matches_separate_launches(dev, ref_cfg, kind, cin, c
         ops.FUSE_1X1_BACKWARD, ops.FUSE_1X1_MIN_PIXELS = keep
     assert launches[True].get("conv1x1_bwd", 0) >= 1 and "conv1x1_bwd" not in launches[False], launches
     assert launches[True].get("conv1x1_wgrad", 0) < launches[False].get("conv1x1_wgrad", 0), launches
-    assert torch.equal(res[True][0], res[False][0])
+    # (the two forwards differ only through the float-atomic order of the BatchNorm statistics: last-bit bf16 flips)
+    assert float((res[True][0] - res[False][0]).norm() / res[False][0].norm()) <= 2e-3
     wnorm = max(float(v.norm()) for k, v in res[False][1].items() if k not in ("x", "yv"))
     for k, ref in res[False][1].items():
         got = res[True][1][k]
