@@ -14,6 +14,9 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+FUSED = True        # stage-wise fused HIP kernels for the encoder block (False: op by op, the path the > 64-token joint pass takes)
+
+
 def _lin(layer, x, recs, name):
     if recs is not None and name in recs:
         return layer.fused(x, recs[name])
@@ -69,7 +72,28 @@ class EncoderBlock(nn.Module):
         self.norm2 = nn.LayerNorm(input_dim)
         self.dropout = nn.Dropout(dropout)
 
+    def _fusable(self, x):
+        """The stage-wise fused HIP block (ops.RRMBlockFn) takes <= 64 tokens per event (attention affinity in LDS) and channel
+        counts that are multiples of 16; anything else (e.g. the 80 / 120 tokens of a joint fake + real pass) runs op by op."""
+        at = self.self_attn
+        dims = (at.qkv_proj.in_features, at.qkv_proj.out_features, self.linear_net[0].out_features)
+        return x.is_cuda and x.dim() == 3 and x.shape[1] <= 64 and all(d % 16 == 0 for d in dims) and dims[1] == 3 * dims[0] \
+            and at.o_proj.in_features == at.o_proj.out_features == dims[0] and self.linear_net[3].out_features == dims[0]
+
     def forward(self, x, recs=None, prefix=""):
+        if FUSED and self._fusable(x):
+            import ops
+            at, ln = self.self_attn, self.linear_net
+            names = [prefix + ".self_attn.qkv_proj", prefix + ".self_attn.o_proj", prefix + ".linear_net.0", prefix + ".linear_net.3"]
+            layers_ = (at.qkv_proj, at.o_proj, ln[0], ln[3])
+            sn = hasattr(at.qkv_proj, "_record")                       # spectrally normalised flavour (D): normalised weights of this pass
+            if sn:
+                rl = [recs[n] if (recs is not None and n in recs) else l._record() for n, l in zip(names, layers_)]
+            else:
+                rl = None
+            return ops.RRMBlockFn.apply(x, at.num_heads, self.norm1.eps, rl, self.norm1.weight, self.norm1.bias, at.qkv_proj.weight,
+                                        at.qkv_proj.bias, at.o_proj.weight, at.o_proj.bias, self.norm2.weight, self.norm2.bias,
+                                        ln[0].weight, ln[0].bias, ln[3].weight, ln[3].bias)
         x = x + self.self_attn(self.norm1(x), recs=recs, prefix=prefix + ".self_attn")
         h = _lin(self.linear_net[0], self.norm2(x), recs, prefix + ".linear_net.0")
         h = _lin(self.linear_net[3], F.relu(h), recs, prefix + ".linear_net.3")
@@ -85,6 +109,9 @@ class RelationalReasoning(nn.Module):
     def forward(self, x, recs=None, prefix=""):
         for i, l in enumerate(self.layers):
             x = l(x, recs=recs, prefix=f"{prefix}.layers.{i}")
+        if FUSED and x.is_cuda:
+            import ops
+            return ops.LayerNormFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps)
         return self.norm(x)
 
     def get_attention_maps(self, x):

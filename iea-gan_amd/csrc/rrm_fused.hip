@@ -1,0 +1,320 @@
+// Stage-wise fused kernels of the Relational Reasoning Module (reference RRM.py:66-133: pre-LN encoder block over the 40 sensor tokens
+// of an event) and of the other small fp32 linear layers around it.  The block runs as
+//     [LayerNorm + qkv projection] -> [attention core, small_ops.hip] -> [o projection + residual] -> [LayerNorm + FFN1 + ReLU]
+//     -> [FFN2 + residual] -> [final LayerNorm]
+// i.e. six launches instead of ~13 library kernels, and backward as eight (slin_bwd: data gradient, weight gradient and bias
+// gradient of one linear layer in ONE launch; ln_bwd: LayerNorm backward + residual-path add + d gamma / d beta).
+// M = B * S rows (40 ... 160), K, N <= 1536: latency-bound work, so the point is launch count, not FLOP/s -- but the arithmetic is
+// exact fp32 on the matrix cores (v_mfma_f32_16x16x4_f32 == an ordered fmaf chain), which keeps the 1e-4 parity with the reference.
+//
+// MFMA 16x16x4 f32 lane map: A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15], D[row = 4 * (l >> 4) + r][col = l & 15].
+// "float4 trick": a lane loads 4 consecutive k of its row (16 bytes) and feeds element t of both operands to MFMA number t -- slot
+// q of MFMA t then stands for k = 16 s + 4 q + t on both sides, so four MFMAs consume one 16-byte load per operand.
+#include "common.h"
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+struct SlinFwdArgs {
+    const float* X;       // [M, K]
+    const float* W;       // [N, K]   (nn.Linear layout; for an SN layer the normalised weight of this pass)
+    const float* b;       // [N] or NULL
+    const float* R;       // [M, N] residual added after bias / ReLU, or NULL
+    float* Y;             // [M, N]
+    const float* ln_g;    // LayerNorm prologue on the rows of X: gamma / beta [K], or NULL
+    const float* ln_b;
+    float* xhat;          // [M, K] normalised rows (saved for the backward), with ln_g
+    float* rstd;          // [M]
+    int M, K, N, relu;
+    float eps;
+};
+
+__global__ __launch_bounds__(256) void slin_fwd_kernel(SlinFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];       // [16][K + 4]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int M = a.M, K = a.K, N = a.N, KS = K + 4;
+    const int m0 = blockIdx.x * 16;
+    const int n0 = blockIdx.y * 64 + wave * 16;
+    for (int idx = threadIdx.x; idx < 16 * (K >> 2); idx += 256) {
+        const int r = idx / (K >> 2), c4 = idx - r * (K >> 2);
+        f32x4v v = {0.f, 0.f, 0.f, 0.f};
+        if (m0 + r < M) v = *(const f32x4v*)(a.X + (long)(m0 + r) * K + c4 * 4);
+        *(f32x4v*)(xs + r * KS + c4 * 4) = v;
+    }
+    __syncthreads();
+    if (a.ln_g != nullptr) {                     // LayerNorm (biased variance, eps inside the root) on rows wave*4 .. wave*4+3
+#pragma unroll 1
+        for (int rr = 0; rr < 4; ++rr) {
+            const int row = wave * 4 + rr;
+            float s = 0.f;
+            for (int c = lane; c < K; c += 64) s += xs[row * KS + c];
+            const float mean = wave_sum(s) / (float)K;
+            float q = 0.f;
+            for (int c = lane; c < K; c += 64) {
+                const float d = xs[row * KS + c] - mean;
+                q += d * d;
+            }
+            const float rstd = rsqrtf(wave_sum(q) / (float)K + a.eps);
+            const bool save = blockIdx.y == 0 && m0 + row < M;
+            for (int c = lane; c < K; c += 64) {
+                const float xh = (xs[row * KS + c] - mean) * rstd;
+                if (save) a.xhat[(long)(m0 + row) * K + c] = xh;
+                xs[row * KS + c] = xh * a.ln_g[c] + a.ln_b[c];
+            }
+            if (save && lane == 0) a.rstd[m0 + row] = rstd;
+        }
+        __syncthreads();
+    }
+    if (n0 >= N) return;                         // (N % 16 == 0: a wave's n-tile is whole or absent)
+    f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+    const float* wrow = a.W + (long)(n0 + i) * K + 4 * kq;
+    const float* xrow = xs + i * KS + 4 * kq;
+#pragma unroll 4
+    for (int s = 0; s < (K >> 4); ++s) {
+        const f32x4v xa = *(const f32x4v*)(xrow + 16 * s);
+        const f32x4v wb = *(const f32x4v*)(wrow + 16 * s);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[0], wb[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[1], wb[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[2], wb[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[3], wb[3], acc, 0, 0, 0);
+    }
+    const int n = n0 + i;
+    const float bias = a.b != nullptr ? a.b[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = m0 + 4 * kq + r;
+        if (m >= M) continue;
+        float v = acc[r] + bias;
+        if (a.relu) v = fmaxf(v, 0.f);
+        if (a.R != nullptr) v += a.R[(long)m * N + n];
+        a.Y[(long)m * N + n] = v;
+    }
+}
+
+struct SlinBwdArgs {
+    const float* dY;      // [M, N]
+    const float* Ymask;   // [M, N] post-ReLU forward output (dY is masked where it is <= 0) or NULL
+    const float* Xn;      // [M, K] the GEMM input; NULL: xhat * ln_g + ln_b
+    const float* xhat;
+    const float* ln_g;
+    const float* ln_b;
+    const float* W;       // [N, K]
+    float* dX;            // [M, K] gradient w.r.t. the GEMM input (= w.r.t. the LayerNorm OUTPUT when the prologue was a LayerNorm), or NULL
+    float* dW;            // [N, K] (assigned) or NULL
+    float* db;            // [N] (assigned) or NULL
+    int M, K, N;
+    int nbx;              // blocks [0, nbx) compute dX tiles, the others dW (+ db) tiles
+    int ktiles;           // 64-wide k tiles of a dX row block
+    int wktiles;          // 64-wide k tiles of a dW row block (1 when only db is wanted)
+};
+
+__device__ __forceinline__ float slin_dy(const SlinBwdArgs& a, int m, int n) {
+    if (m >= a.M) return 0.f;
+    const float g = a.dY[(long)m * a.N + n];
+    return (a.Ymask != nullptr && !(a.Ymask[(long)m * a.N + n] > 0.f)) ? 0.f : g;
+}
+
+__device__ __forceinline__ float slin_xn(const SlinBwdArgs& a, int m, int k) {
+    if (m >= a.M) return 0.f;
+    if (a.Xn != nullptr) return a.Xn[(long)m * a.K + k];
+    return a.xhat[(long)m * a.K + k] * a.ln_g[k] + a.ln_b[k];
+}
+
+__global__ __launch_bounds__(256) void slin_bwd_kernel(SlinBwdArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int M = a.M, K = a.K, N = a.N;
+    if ((int)blockIdx.x < a.nbx) {
+        // ---- dX[m0 .. m0+16, k0 .. k0+16) = dY W: reduction over n.  A: lane (row i, slot q) holds dY[m0+i][16s + 4q + t];
+        //      B: lane (col i, slot q) holds W[16s + 4q + t][k0 + i]
+        const int mt = blockIdx.x / a.ktiles, kt = blockIdx.x - mt * a.ktiles;
+        const int m0 = mt * 16, k0 = kt * 64 + wave * 16;
+        if (k0 >= K) return;
+        const bool mok = m0 + i < M;
+        f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+        const float* dyrow = a.dY + (long)(mok ? m0 + i : 0) * N + 4 * q;
+        const float* ymrow = a.Ymask != nullptr ? a.Ymask + (long)(mok ? m0 + i : 0) * N + 4 * q : nullptr;
+#pragma unroll 2
+        for (int s = 0; s < (N >> 4); ++s) {
+            f32x4v ga = *(const f32x4v*)(dyrow + 16 * s);
+            if (ymrow != nullptr) {
+                const f32x4v ym = *(const f32x4v*)(ymrow + 16 * s);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) ga[t] = ym[t] > 0.f ? ga[t] : 0.f;
+            }
+            if (!mok) ga = (f32x4v){0.f, 0.f, 0.f, 0.f};
+            const float* wp = a.W + (long)(16 * s + 4 * q) * K + k0 + i;
+            const float w0 = wp[0], w1 = wp[K], w2 = wp[2 * (long)K], w3 = wp[3 * (long)K];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[0], w0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[1], w1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[2], w2, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[3], w3, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 4 * q + r;
+            if (m < M) a.dX[(long)m * K + k0 + i] = acc[r];
+        }
+        return;
+    }
+    // ---- dW[n0 .. n0+16, k0 .. k0+64) = dY^T Xn: reduction over m.  A: lane (row i = n, slot q) holds dY[4t + q][n0 + i];
+    //      B: lane (col i = k, slot q) holds Xn[4t + q][k0 + 16 jj + i].  db[n] = sum_m dY[m][n] rides on the k0 == 0 tiles.
+    const int bw = blockIdx.x - a.nbx;
+    const int nt = bw / a.wktiles, kt = bw - nt * a.wktiles;
+    const int n0 = nt * 64 + wave * 16, k0 = kt * 64;
+    if (n0 >= N) return;
+    f32x4v acc[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) acc[jj] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    for (int t = 0; t < ((M + 3) >> 2); ++t) {
+        const int m = 4 * t + q;
+        const float ga = slin_dy(a, m, n0 + i);
+        bsum += ga;
+        if (a.dW == nullptr) continue;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int k = k0 + 16 * jj + i;
+            const float xb = (k < K) ? slin_xn(a, m, k) : 0.f;
+            acc[jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga, xb, acc[jj], 0, 0, 0);
+        }
+    }
+    if (a.dW != nullptr) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + 4 * q + r, k = k0 + 16 * jj + i;
+                if (k < K) a.dW[(long)n * K + k] = acc[jj][r];
+            }
+    }
+    if (a.db != nullptr && k0 == 0) {
+        bsum += __shfl_xor(bsum, 16, 64);
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (q == 0) a.db[n0 + i] = bsum;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm forward (stand-alone: the final norm of the module) and backward; one block per row.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float blk_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float s = red[0] + red[1] + red[2] + red[3];
+    return s;
+}
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ X, const float* __restrict__ g, const float* __restrict__ b,
+                                                      float* __restrict__ Y, float* __restrict__ xhat, float* __restrict__ rstd_out, int K, float eps,
+                                                      int l2norm) {
+    __shared__ float red[4];
+    const int m = blockIdx.x;
+    const float* x = X + (long)m * K;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < K; c += 256) s += x[c];
+    const float mean = blk_sum(s, red) / (float)K;
+    float q = 0.f;
+    for (int c = threadIdx.x; c < K; c += 256) {
+        const float d = x[c] - mean;
+        q += d * d;
+    }
+    const float rstd = rsqrtf(blk_sum(q, red) / (float)K + eps);
+    float nn = 0.f;
+    for (int c = threadIdx.x; c < K; c += 256) {
+        const float xh = (x[c] - mean) * rstd;
+        const float y = xh * g[c] + b[c];
+        xhat[(long)m * K + c] = xh;
+        if (!l2norm) Y[(long)m * K + c] = y;
+        nn += y * y;
+    }
+    if (threadIdx.x == 0) rstd_out[m] = rstd;
+    if (l2norm) {                                 // F.normalize(., dim = 1) of the LayerNorm output (model.py:920-935), eps 1e-12
+        const float inv = 1.f / fmaxf(sqrtf(blk_sum(nn, red)), 1e-12f);
+        for (int c = threadIdx.x; c < K; c += 256) Y[(long)m * K + c] = (xhat[(long)m * K + c] * g[c] + b[c]) * inv;
+    }
+}
+
+// dX = rstd * (dxh - mean(dxh) - xhat * mean(dxh * xhat)) + dRes,  dxh = dY * gamma;   dgamma += dY * xhat, dbeta += dY  (atomics over rows)
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ xhat, const float* __restrict__ rstd,
+                                                      const float* __restrict__ g, const float* __restrict__ dRes, float* __restrict__ dX,
+                                                      float* __restrict__ dg, float* __restrict__ dbeta, int K) {
+    __shared__ float red[4];
+    const int m = blockIdx.x;
+    const float* dy = dY + (long)m * K;
+    const float* xh = xhat + (long)m * K;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = threadIdx.x; c < K; c += 256) {
+        const float d = dy[c] * g[c];
+        s1 += d;
+        s2 += d * xh[c];
+    }
+    s1 = blk_sum(s1, red) / (float)K;
+    s2 = blk_sum(s2, red) / (float)K;
+    const float r = rstd[m];
+    for (int c = threadIdx.x; c < K; c += 256) {
+        const float d = dy[c] * g[c];
+        float v = r * (d - s1 - xh[c] * s2);
+        if (dRes != nullptr) v += dRes[(long)m * K + c];
+        dX[(long)m * K + c] = v;
+        if (dg != nullptr) {
+            atomicAdd(dg + c, dy[c] * xh[c]);
+            atomicAdd(dbeta + c, dy[c]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int ieagan_slin_fwd(const float* X, const float* W, const float* b, const float* R, float* Y, const float* ln_g, const float* ln_b,
+                               float* xhat, float* rstd, int M, int K, int N, int relu, float eps, void* stream) {
+    CHECK_ARG(X != nullptr && W != nullptr && Y != nullptr, "slin_fwd: null pointer");
+    CHECK_ARG(M >= 1 && K >= 16 && K % 16 == 0 && N >= 16 && N % 16 == 0 && K <= 2048, "slin_fwd: M=%d K=%d N=%d (K, N multiples of 16, K <= 2048)", M, K, N);
+    CHECK_ARG((ln_g == nullptr) == (ln_b == nullptr) && (ln_g == nullptr || (xhat != nullptr && rstd != nullptr)), "slin_fwd: LayerNorm prologue needs gamma, beta, xhat, rstd");
+    SlinFwdArgs a{X, W, b, R, Y, ln_g, ln_b, xhat, rstd, M, K, N, relu, eps};
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof("slin_fwd", 2.0 * M * (double)K * N, 4.0 * ((double)M * K + (double)N * K + (double)M * N), st);
+    const size_t lds = (size_t)16 * (K + 4) * 4;
+    hipLaunchKernelGGL(slin_fwd_kernel, dim3((M + 15) / 16, (N + 63) / 64), dim3(256), lds, st, a);
+    CHECK_LAUNCH("slin_fwd");
+    return 0;
+}
+
+extern "C" int ieagan_slin_bwd(const float* dY, const float* Ymask, const float* Xn, const float* xhat, const float* ln_g, const float* ln_b,
+                               const float* W, float* dX, float* dW, float* db, int M, int K, int N, void* stream) {
+    CHECK_ARG(dY != nullptr && W != nullptr, "slin_bwd: null pointer");
+    CHECK_ARG(M >= 1 && K >= 16 && K % 16 == 0 && N >= 16 && N % 16 == 0, "slin_bwd: M=%d K=%d N=%d (K, N multiples of 16)", M, K, N);
+    CHECK_ARG(Xn != nullptr || (xhat != nullptr && ln_g != nullptr && ln_b != nullptr) || (dW == nullptr), "slin_bwd: the weight gradient needs the GEMM input");
+    CHECK_ARG(dX != nullptr || dW != nullptr || db != nullptr, "slin_bwd: nothing to compute");
+    const int ktiles = (K + 63) / 64, mtiles = (M + 15) / 16;
+    const int wktiles = dW != nullptr ? ktiles : 1;
+    SlinBwdArgs a{dY, Ymask, Xn, xhat, ln_g, ln_b, W, dX, dW, db, M, K, N, dX != nullptr ? mtiles * ktiles : 0, ktiles, wktiles};
+    const int nbw = (dW != nullptr || db != nullptr) ? ((N + 63) / 64) * wktiles : 0;
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof("slin_bwd", 2.0 * M * (double)K * N * ((dX ? 1 : 0) + (dW ? 1 : 0)), 4.0 * ((double)M * K + 2.0 * N * K + (double)M * N), st);
+    hipLaunchKernelGGL(slin_bwd_kernel, dim3(a.nbx + nbw), dim3(256), 0, st, a);
+    CHECK_LAUNCH("slin_bwd");
+    return 0;
+}
+
+extern "C" int ieagan_ln_fwd(const float* X, const float* g, const float* b, float* Y, float* xhat, float* rstd, int M, int K, float eps, int l2norm,
+                             void* stream) {
+    CHECK_ARG(X != nullptr && g != nullptr && b != nullptr && Y != nullptr && xhat != nullptr && rstd != nullptr && M >= 1 && K >= 1, "ln_fwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof("ln_fwd", 0.0, 12.0 * M * K, st);
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3(M), dim3(256), 0, st, X, g, b, Y, xhat, rstd, K, eps, l2norm);
+    CHECK_LAUNCH("ln_fwd");
+    return 0;
+}
+
+extern "C" int ieagan_ln_bwd(const float* dY, const float* xhat, const float* rstd, const float* g, const float* dRes, float* dX, float* dg, float* dbeta,
+                             int M, int K, void* stream) {
+    CHECK_ARG(dY != nullptr && xhat != nullptr && rstd != nullptr && g != nullptr && dX != nullptr && M >= 1 && K >= 1, "ln_bwd: bad arguments");
+    CHECK_ARG((dg == nullptr) == (dbeta == nullptr), "ln_bwd: d gamma / d beta come together");
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof("ln_bwd", 0.0, 16.0 * M * K, st);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(M), dim3(256), 0, st, dY, xhat, rstd, g, dRes, dX, dg, dbeta, K);
+    CHECK_LAUNCH("ln_bwd");
+    return 0;
+}

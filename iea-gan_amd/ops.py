@@ -1137,6 +1137,127 @@ class RRMAttentionFn(torch.autograd.Function):
         return dqkv, None
 
 
+def _slin_fwd(x, w, b, res, ln_w=None, ln_b=None, relu=False, eps=1e-5):
+    """y = [relu](LN?(x) @ w^T + b) [+ res] in one launch (csrc/rrm_fused.hip); returns (y, xhat, rstd)."""
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    xhat = rstd = None
+    if ln_w is not None:
+        xhat = torch.empty(M, K, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+    H.call("ieagan_slin_fwd", x.data_ptr(), w.data_ptr(), H.ptr(b), H.ptr(res), y.data_ptr(), H.ptr(ln_w), H.ptr(ln_b), H.ptr(xhat), H.ptr(rstd),
+           M, K, N, int(relu), float(eps), H.stream())
+    return y, xhat, rstd
+
+
+def _slin_bwd(dy, w, xn=None, xhat=None, ln_w=None, ln_b=None, ymask=None, want_dx=True, want_dw=True, want_db=True):
+    """(dx, dw, db) of one linear layer in one launch: dx = dy' w, dw = dy'^T xn, db = column sums of dy' (dy' = dy masked where
+    ``ymask`` <= 0; xn = the GEMM input, or xhat * ln_w + ln_b)."""
+    M, N = dy.shape
+    K = w.shape[1]
+    dev = dy.device
+    dx = torch.empty(M, K, dtype=torch.float32, device=dev) if want_dx else None
+    dw = torch.empty(N, K, dtype=torch.float32, device=dev) if want_dw else None
+    db = torch.empty(N, dtype=torch.float32, device=dev) if want_db else None
+    if dx is None and dw is None and db is None:
+        return None, None, None
+    H.call("ieagan_slin_bwd", dy.data_ptr(), H.ptr(ymask), H.ptr(xn), H.ptr(xhat), H.ptr(ln_w), H.ptr(ln_b), w.data_ptr(), H.ptr(dx), H.ptr(dw),
+           H.ptr(db), M, K, N, H.stream())
+    return dx, dw, db
+
+
+def _ln_bwd(dy, xhat, rstd, w, dres=None, want_param=True):
+    M, K = dy.shape
+    dx = torch.empty_like(dy)
+    dg = zeros((K,), dy.device) if want_param else None
+    dbeta = zeros((K,), dy.device) if want_param else None
+    H.call("ieagan_ln_bwd", dy.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), w.data_ptr(), H.ptr(dres), dx.data_ptr(), H.ptr(dg), H.ptr(dbeta), M, K,
+           H.stream())
+    return dx, dg, dbeta
+
+
+class LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm over the last dimension of [M, K] rows in one launch; ``l2norm``: followed by F.normalize(., dim=1) (the
+    discriminator's embedding head, model.py:920-935)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps, l2norm=False):
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1]).contiguous().float()
+        M, K = x2.shape
+        y = torch.empty_like(x2)
+        xhat = torch.empty_like(x2)
+        rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+        H.call("ieagan_ln_fwd", x2.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), M, K, float(eps),
+               int(l2norm), H.stream())
+        ctx.shape, ctx.l2norm = shape, l2norm
+        ctx.save_for_backward(xhat, rstd, w, b, y if l2norm else None)
+        return y.view(shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xhat, rstd, w, b, y = ctx.saved_tensors
+        g = dy.reshape(-1, ctx.shape[-1]).contiguous().float()
+        if ctx.l2norm:          # y = u / |u|:  du = (dy - y <dy, y>) / |u|, with |u| recovered from u = xhat * w + b
+            u = xhat * w + b
+            nrm = u.norm(dim=1, keepdim=True).clamp_min(1e-12)
+            g = (g - y * (g * y).sum(1, keepdim=True)) / nrm
+        need = ctx.needs_input_grad
+        dx, dg, dbeta = _ln_bwd(g, xhat, rstd, w, None, need[1] or need[2])
+        return dx.view(ctx.shape), dg, dbeta, None, None
+
+
+class RRMBlockFn(torch.autograd.Function):
+    """One pre-LN encoder block of the Relational Reasoning Module (reference RRM.py:66-109) on [B, S <= 64, E] tokens, stage-wise
+    fused: [LN1 + qkv] -> [attention core] -> [o proj + residual] -> [LN2 + FFN1 + ReLU] -> [FFN2 + residual]: five launches
+    forward, seven backward (+ one per spectrally normalised weight).  ``params`` = (norm1.w, norm1.b, qkv.w, qkv.b, o.w, o.b,
+    norm2.w, norm2.b, ffn1.w, ffn1.b, ffn2.w, ffn2.b); ``recs``: the four SNRecords of the linear layers (SNLinear flavour, D) or
+    None (nn.Linear, G)."""
+
+    @staticmethod
+    def forward(ctx, x, heads, eps, recs, *params):
+        n1w, n1b, wq, bq, wo, bo, n2w, n2b, w1, b1, w2, b2 = params
+        B, S, E = x.shape
+        M = B * S
+        x2d = x.reshape(M, E).contiguous().float()
+        eff = [wq, wo, w1, w2] if recs is None else [r.w_plain.view(w.shape) for r, w in zip(recs, (wq, wo, w1, w2))]
+        qkv, xhat1, rstd1 = _slin_fwd(x2d, eff[0], bq, None, n1w, n1b, False, eps)
+        hd = E // heads
+        vals = torch.empty(M, E, dtype=torch.float32, device=x.device)
+        att = torch.empty(B, heads, S, S, dtype=torch.float32, device=x.device)
+        H.call("ieagan_rrm_attention_fwd", qkv.data_ptr(), vals.data_ptr(), att.data_ptr(), B, S, heads, hd, H.stream())
+        xa, _, _ = _slin_fwd(vals, eff[1], bo, x2d)
+        h, xhat2, rstd2 = _slin_fwd(xa, eff[2], b1, None, n2w, n2b, True, eps)
+        out, _, _ = _slin_fwd(h, eff[3], b2, xa)
+        ctx.recs, ctx.cfg = recs, (B, S, E, heads, hd)
+        ctx.save_for_backward(xhat1, rstd1, qkv, att, vals, xhat2, rstd2, h, *eff, *params)
+        return out.view(B, S, E)
+
+    @staticmethod
+    def backward(ctx, dout):
+        xhat1, rstd1, qkv, att, vals, xhat2, rstd2, h, eq, eo, e1, e2, *params = ctx.saved_tensors
+        n1w, n1b, wq, bq, wo, bo, n2w, n2b, w1, b1, w2, b2 = params
+        B, S, E, heads, hd = ctx.cfg
+        M = B * S
+        need = ctx.needs_input_grad[4:]               # aligned with ``params``
+        g = dout.reshape(M, E).contiguous().float()
+        dh, dw2, db2 = _slin_bwd(g, e2, xn=h, want_dw=need[10], want_db=need[11])
+        dxn2, dw1, db1 = _slin_bwd(dh, e1, xhat=xhat2, ln_w=n2w, ln_b=n2b, ymask=h, want_dw=need[8], want_db=need[9])
+        dxa, dn2w, dn2b = _ln_bwd(dxn2, xhat2, rstd2, n2w, g, need[6] or need[7])
+        dvals, dwo, dbo = _slin_bwd(dxa, eo, xn=vals, want_dw=need[4], want_db=need[5])
+        dqkv = torch.empty_like(qkv)
+        H.call("ieagan_rrm_attention_bwd", qkv.data_ptr(), att.data_ptr(), dvals.data_ptr(), dqkv.data_ptr(), B, S, heads, hd, H.stream())
+        dxn1, dwq, dbq = _slin_bwd(dqkv, eq, xhat=xhat1, ln_w=n1w, ln_b=n1b, want_dw=need[2], want_db=need[3])
+        dx, dn1w, dn1b = _ln_bwd(dxn1, xhat1, rstd1, n1w, dxa, need[0] or need[1])
+        dws = [dwq, dwo, dw1, dw2]
+        if ctx.recs is not None:                      # gradient of W / sigma -> gradient of W (incl. the sigma term), one launch per layer
+            for k, (r, w) in enumerate(zip(ctx.recs, (wq, wo, w1, w2))):
+                if dws[k] is not None:
+                    dws[k] = sn_backward(dws[k], w, r)[0]
+        return (dx.view(B, S, E), None, None, None, dn1w, dn1b, dws[0], dbq, dws[1], dbo, dn2w, dn2b, dws[2], db1, dws[3], db2)
+
+
 class LossBlockFn(torch.autograd.Function):
     """All losses of one phase, value and gradient, in one launch (loss.py:8-44, 79-132).
     Returns (total, terms[8]); only ``total`` is differentiable."""

@@ -223,6 +223,20 @@ int ieagan_nl_attention_bwd(const void* Q, const void* K, const void* V, const v
 int ieagan_rrm_attention_fwd(const float* qkv, float* out, float* att, int B, int S, int H, int hd, void* stream);
 int ieagan_rrm_attention_bwd(const float* qkv, const float* att, const float* dout, float* dqkv, int B, int S, int H, int hd,
                              void* stream);
+/* Stage-wise fused linear layers of the Relational Reasoning Module and the heads (rrm_fused.hip), fp32, exact on the fp32 matrix cores.
+ * Replaces nn.LayerNorm + nn.Linear / SNLinear + ReLU + residual add chains (reference RRM.py:85-109, 118-125; model.py:915-921):
+ *   slin_fwd:  Y[M,N] = [relu]( LN?(X)[M,K] W[N,K]^T + b ) [+ R]     LN: rows of X normalised with gamma / beta (eps), xhat [M,K] / rstd [M] saved
+ *   slin_bwd:  dY' = dY masked where Ymask <= 0;  dX[M,K] = dY' W,  dW[N,K] = dY'^T Xn,  db[N] = column sums of dY'   (Xn NULL: xhat*ln_g+ln_b)
+ *   ln_fwd:    nn.LayerNorm rows (+ F.normalize(., dim=1) with l2norm);   ln_bwd: its backward + dRes (residual path), dg / dbeta accumulated
+ * K, N multiples of 16. */
+int ieagan_slin_fwd(const float* X, const float* W, const float* b, const float* R, float* Y, const float* ln_g, const float* ln_b,
+                    float* xhat, float* rstd, int M, int K, int N, int relu, float eps, void* stream);
+int ieagan_slin_bwd(const float* dY, const float* Ymask, const float* Xn, const float* xhat, const float* ln_g, const float* ln_b,
+                    const float* W, float* dX, float* dW, float* db, int M, int K, int N, void* stream);
+int ieagan_ln_fwd(const float* X, const float* g, const float* b, float* Y, float* xhat, float* rstd, int M, int K, float eps, int l2norm,
+                  void* stream);
+int ieagan_ln_bwd(const float* dY, const float* xhat, const float* rstd, const float* g, const float* dRes, float* dX, float* dg, float* dbeta,
+                  int M, int K, void* stream);
 /* all losses of one phase, value and gradient, one launch (loss.py:8-44, 79-132); weights6 (host) = weights of
  * {hinge_real, hinge_fake, hinge_gen, contrastive, uniformity, IEA}; vals8 (device) = {total, the six terms, 0} */
 int ieagan_loss_block(const float* dfake, const float* dreal, const float* e, const float* p, const float* er,
