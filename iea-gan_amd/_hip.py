@@ -88,9 +88,11 @@ _SIGS = {
     "ieagan_rrm_attention_fwd": [vp, vp, vp, i, i, i, i, vp],
     "ieagan_rrm_attention_bwd": [vp, vp, vp, vp, i, i, i, i, vp],
     "ieagan_slin_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, f, vp],
-    "ieagan_slin_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, vp],
+    "ieagan_slin_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, vp],
     "ieagan_ln_fwd": [vp, vp, vp, vp, vp, vp, i, i, f, i, vp],
-    "ieagan_ln_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, i, i, vp],
+    "ieagan_ln_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, vp],
+    "ieagan_embed_norm_fwd": [vp, vp, vp, vp, i, i, vp],
+    "ieagan_embed_norm_bwd": [vp, vp, vp, vp, vp, i, i, vp],
     "ieagan_loss_block": [vp, vp, vp, vp, vp, C.POINTER(C.c_float), f, vp, vp, vp, vp, vp, i, i, vp],
     "ieagan_relu_sum_pool": [vp, vp, i, i, i, vp],
     "ieagan_relu_sum_pool_bwd": [vp, vp, vp, i, i, i, vp],

@@ -32,13 +32,14 @@ __global__ __launch_bounds__(256) void slin_fwd_kernel(SlinFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float xs[];       // [16][K + 4]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, kq = lane >> 4;
-    const int M = a.M, K = a.K, N = a.N, KS = K + 4;
+    const int M = a.M, K = a.K, N = a.N;
+    const int K16 = (K + 15) & ~15, KS = K16 + 4;                    // rows zero-padded to whole 16-wide k groups
     const int m0 = blockIdx.x * 16;
     const int n0 = blockIdx.y * 64 + wave * 16;
-    for (int idx = threadIdx.x; idx < 16 * (K >> 2); idx += 256) {
-        const int r = idx / (K >> 2), c4 = idx - r * (K >> 2);
+    for (int idx = threadIdx.x; idx < 16 * (K16 >> 2); idx += 256) {
+        const int r = idx / (K16 >> 2), c4 = idx - r * (K16 >> 2);
         f32x4v v = {0.f, 0.f, 0.f, 0.f};
-        if (m0 + r < M) v = *(const f32x4v*)(a.X + (long)(m0 + r) * K + c4 * 4);
+        if (m0 + r < M && c4 * 4 < K) v = *(const f32x4v*)(a.X + (long)(m0 + r) * K + c4 * 4);
         *(f32x4v*)(xs + r * KS + c4 * 4) = v;
     }
     __syncthreads();
@@ -65,20 +66,23 @@ __global__ __launch_bounds__(256) void slin_fwd_kernel(SlinFwdArgs a) {
         }
         __syncthreads();
     }
-    if (n0 >= N) return;                         // (N % 16 == 0: a wave's n-tile is whole or absent)
+    if (n0 >= N) return;
+    const bool nok = n0 + i < N;                 // (a partly filled n-tile: N = 1 for the discriminator's logit layer)
     f32x4v acc = {0.f, 0.f, 0.f, 0.f};
-    const float* wrow = a.W + (long)(n0 + i) * K + 4 * kq;
+    const float* wrow = a.W + (long)(nok ? n0 + i : 0) * K + 4 * kq;
     const float* xrow = xs + i * KS + 4 * kq;
 #pragma unroll 4
-    for (int s = 0; s < (K >> 4); ++s) {
+    for (int s = 0; s < (K16 >> 4); ++s) {
         const f32x4v xa = *(const f32x4v*)(xrow + 16 * s);
-        const f32x4v wb = *(const f32x4v*)(wrow + 16 * s);
+        f32x4v wb = {0.f, 0.f, 0.f, 0.f};
+        if (nok && 16 * s + 4 * kq < K) wb = *(const f32x4v*)(wrow + 16 * s);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[0], wb[0], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[1], wb[1], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[2], wb[2], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[3], wb[3], acc, 0, 0, 0);
     }
     const int n = n0 + i;
+    if (!nok) return;
     const float bias = a.b != nullptr ? a.b[n] : 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -106,6 +110,8 @@ struct SlinBwdArgs {
     int nbx;              // blocks [0, nbx) compute dX tiles, the others dW (+ db) tiles
     int ktiles;           // 64-wide k tiles of a dX row block
     int wktiles;          // 64-wide k tiles of a dW row block (1 when only db is wanted)
+    int nsplit;           // > 1: the reduction over n of a dX tile is cut into nsplit ranges of nchunk (multiple of 16) columns, partial
+    int nchunk;           //      tiles are ADDED to the caller-zeroed dX with float atomics (N = 24576 of G.linear: 48 x 512)
 };
 
 __device__ __forceinline__ float slin_dy(const SlinBwdArgs& a, int m, int n) {
@@ -127,33 +133,48 @@ __global__ __launch_bounds__(256) void slin_bwd_kernel(SlinBwdArgs a) {
     if ((int)blockIdx.x < a.nbx) {
         // ---- dX[m0 .. m0+16, k0 .. k0+16) = dY W: reduction over n.  A: lane (row i, slot q) holds dY[m0+i][16s + 4q + t];
         //      B: lane (col i, slot q) holds W[16s + 4q + t][k0 + i]
-        const int mt = blockIdx.x / a.ktiles, kt = blockIdx.x - mt * a.ktiles;
+        const int tile = blockIdx.x / a.nsplit, ns = blockIdx.x - tile * a.nsplit;
+        const int mt = tile / a.ktiles, kt = tile - mt * a.ktiles;
         const int m0 = mt * 16, k0 = kt * 64 + wave * 16;
         if (k0 >= K) return;
-        const bool mok = m0 + i < M;
+        const bool mok = m0 + i < M, kok = k0 + i < K;
+        const int nb = ns * a.nchunk, ne = min(nb + a.nchunk, N);
         f32x4v acc = {0.f, 0.f, 0.f, 0.f};
-        const float* dyrow = a.dY + (long)(mok ? m0 + i : 0) * N + 4 * q;
-        const float* ymrow = a.Ymask != nullptr ? a.Ymask + (long)(mok ? m0 + i : 0) * N + 4 * q : nullptr;
+        if ((N & 15) == 0) {
+            const float* dyrow = a.dY + (long)(mok ? m0 + i : 0) * N + 4 * q;
+            const float* ymrow = a.Ymask != nullptr ? a.Ymask + (long)(mok ? m0 + i : 0) * N + 4 * q : nullptr;
 #pragma unroll 2
-        for (int s = 0; s < (N >> 4); ++s) {
-            f32x4v ga = *(const f32x4v*)(dyrow + 16 * s);
-            if (ymrow != nullptr) {
-                const f32x4v ym = *(const f32x4v*)(ymrow + 16 * s);
+            for (int s = nb >> 4; s < (ne >> 4); ++s) {
+                f32x4v ga = *(const f32x4v*)(dyrow + 16 * s);
+                if (ymrow != nullptr) {
+                    const f32x4v ym = *(const f32x4v*)(ymrow + 16 * s);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) ga[t] = ym[t] > 0.f ? ga[t] : 0.f;
+                    for (int t = 0; t < 4; ++t) ga[t] = ym[t] > 0.f ? ga[t] : 0.f;
+                }
+                if (!mok) ga = (f32x4v){0.f, 0.f, 0.f, 0.f};
+                const float* wp = a.W + (long)(16 * s + 4 * q) * K + (kok ? k0 + i : 0);
+                float w0 = wp[0], w1 = wp[K], w2 = wp[2 * (long)K], w3 = wp[3 * (long)K];
+                if (!kok) w0 = w1 = w2 = w3 = 0.f;
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[0], w0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[1], w1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[2], w2, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[3], w3, acc, 0, 0, 0);
             }
-            if (!mok) ga = (f32x4v){0.f, 0.f, 0.f, 0.f};
-            const float* wp = a.W + (long)(16 * s + 4 * q) * K + k0 + i;
-            const float w0 = wp[0], w1 = wp[K], w2 = wp[2 * (long)K], w3 = wp[3 * (long)K];
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[0], w0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[1], w1, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[2], w2, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[3], w3, acc, 0, 0, 0);
+        } else {                                  // ragged N (N = 1: the logit layer): one guarded column per MFMA slot
+            for (int s = 0; s < ((N + 3) >> 2); ++s) {
+                const int nn = 4 * s + q;
+                const float ga = slin_dy(a, mok ? m0 + i : M, nn < N ? nn : 0) * (nn < N ? 1.f : 0.f);
+                const float wv = (nn < N && kok) ? a.W[(long)nn * K + k0 + i] : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga, wv, acc, 0, 0, 0);
+            }
         }
+        if (!kok) return;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = m0 + 4 * q + r;
-            if (m < M) a.dX[(long)m * K + k0 + i] = acc[r];
+            if (m >= M) continue;
+            if (a.nsplit > 1) atomicAdd(a.dX + (long)m * K + k0 + i, acc[r]);
+            else a.dX[(long)m * K + k0 + i] = acc[r];
         }
         return;
     }
@@ -163,13 +184,14 @@ __global__ __launch_bounds__(256) void slin_bwd_kernel(SlinBwdArgs a) {
     const int nt = bw / a.wktiles, kt = bw - nt * a.wktiles;
     const int n0 = nt * 64 + wave * 16, k0 = kt * 64;
     if (n0 >= N) return;
+    const bool nok = n0 + i < N;
     f32x4v acc[4];
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) acc[jj] = (f32x4v){0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
     for (int t = 0; t < ((M + 3) >> 2); ++t) {
         const int m = 4 * t + q;
-        const float ga = slin_dy(a, m, n0 + i);
+        const float ga = nok ? slin_dy(a, m, n0 + i) : 0.f;
         bsum += ga;
         if (a.dW == nullptr) continue;
 #pragma unroll
@@ -185,13 +207,13 @@ __global__ __launch_bounds__(256) void slin_bwd_kernel(SlinBwdArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int n = n0 + 4 * q + r, k = k0 + 16 * jj + i;
-                if (k < K) a.dW[(long)n * K + k] = acc[jj][r];
+                if (k < K && n < N) a.dW[(long)n * K + k] = acc[jj][r];
             }
     }
     if (a.db != nullptr && k0 == 0) {
         bsum += __shfl_xor(bsum, 16, 64);
         bsum += __shfl_xor(bsum, 32, 64);
-        if (q == 0) a.db[n0 + i] = bsum;
+        if (q == 0 && nok) a.db[n0 + i] = bsum;
     }
 }
 
@@ -238,16 +260,33 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ X
 }
 
 // dX = rstd * (dxh - mean(dxh) - xhat * mean(dxh * xhat)) + dRes,  dxh = dY * gamma;   dgamma += dY * xhat, dbeta += dY  (atomics over rows)
+// beta != NULL: the forward ended with y = u / max(|u|, 1e-12), u = xhat * gamma + beta (F.normalize of the LayerNorm output): dY is then the
+// gradient w.r.t. y and is first mapped to du = (dY - y <dY, y>) / |u|.
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ xhat, const float* __restrict__ rstd,
-                                                      const float* __restrict__ g, const float* __restrict__ dRes, float* __restrict__ dX,
-                                                      float* __restrict__ dg, float* __restrict__ dbeta, int K) {
+                                                      const float* __restrict__ g, const float* __restrict__ beta, const float* __restrict__ dRes,
+                                                      float* __restrict__ dX, float* __restrict__ dg, float* __restrict__ dbeta, int K) {
     __shared__ float red[4];
     const int m = blockIdx.x;
     const float* dy = dY + (long)m * K;
     const float* xh = xhat + (long)m * K;
+    float inv = 1.f, proj = 0.f;                  // du = (dy - u * proj) * inv
+    if (beta != nullptr) {
+        float uu = 0.f, du = 0.f;
+        for (int c = threadIdx.x; c < K; c += 256) {
+            const float u = xh[c] * g[c] + beta[c];
+            uu += u * u;
+            du += dy[c] * u;
+        }
+        uu = blk_sum(uu, red);
+        du = blk_sum(du, red);
+        const float nrm = fmaxf(sqrtf(uu), 1e-12f);
+        inv = 1.f / nrm;
+        proj = du / (nrm * nrm);
+    }
     float s1 = 0.f, s2 = 0.f;
     for (int c = threadIdx.x; c < K; c += 256) {
-        const float d = dy[c] * g[c];
+        const float dyc = beta != nullptr ? (dy[c] - (xh[c] * g[c] + beta[c]) * proj) * inv : dy[c];
+        const float d = dyc * g[c];
         s1 += d;
         s2 += d * xh[c];
     }
@@ -255,13 +294,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     s2 = blk_sum(s2, red) / (float)K;
     const float r = rstd[m];
     for (int c = threadIdx.x; c < K; c += 256) {
-        const float d = dy[c] * g[c];
+        const float dyc = beta != nullptr ? (dy[c] - (xh[c] * g[c] + beta[c]) * proj) * inv : dy[c];
+        const float d = dyc * g[c];
         float v = r * (d - s1 - xh[c] * s2);
         if (dRes != nullptr) v += dRes[(long)m * K + c];
         dX[(long)m * K + c] = v;
         if (dg != nullptr) {
-            atomicAdd(dg + c, dy[c] * xh[c]);
-            atomicAdd(dbeta + c, dy[c]);
+            atomicAdd(dg + c, dyc * xh[c]);
+            atomicAdd(dbeta + c, dyc);
         }
     }
 }
@@ -270,26 +310,33 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 extern "C" int ieagan_slin_fwd(const float* X, const float* W, const float* b, const float* R, float* Y, const float* ln_g, const float* ln_b,
                                float* xhat, float* rstd, int M, int K, int N, int relu, float eps, void* stream) {
     CHECK_ARG(X != nullptr && W != nullptr && Y != nullptr, "slin_fwd: null pointer");
-    CHECK_ARG(M >= 1 && K >= 16 && K % 16 == 0 && N >= 16 && N % 16 == 0 && K <= 2048, "slin_fwd: M=%d K=%d N=%d (K, N multiples of 16, K <= 2048)", M, K, N);
+    CHECK_ARG(M >= 1 && K >= 4 && K % 4 == 0 && N >= 1 && K <= 2048, "slin_fwd: M=%d K=%d N=%d (K a multiple of 4, <= 2048)", M, K, N);
     CHECK_ARG((ln_g == nullptr) == (ln_b == nullptr) && (ln_g == nullptr || (xhat != nullptr && rstd != nullptr)), "slin_fwd: LayerNorm prologue needs gamma, beta, xhat, rstd");
     SlinFwdArgs a{X, W, b, R, Y, ln_g, ln_b, xhat, rstd, M, K, N, relu, eps};
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof("slin_fwd", 2.0 * M * (double)K * N, 4.0 * ((double)M * K + (double)N * K + (double)M * N), st);
-    const size_t lds = (size_t)16 * (K + 4) * 4;
+    const size_t lds = (size_t)16 * (((K + 15) & ~15) + 4) * 4;
     hipLaunchKernelGGL(slin_fwd_kernel, dim3((M + 15) / 16, (N + 63) / 64), dim3(256), lds, st, a);
     CHECK_LAUNCH("slin_fwd");
     return 0;
 }
 
 extern "C" int ieagan_slin_bwd(const float* dY, const float* Ymask, const float* Xn, const float* xhat, const float* ln_g, const float* ln_b,
-                               const float* W, float* dX, float* dW, float* db, int M, int K, int N, void* stream) {
+                               const float* W, float* dX, float* dW, float* db, int M, int K, int N, int dx_zeroed, void* stream) {
     CHECK_ARG(dY != nullptr && W != nullptr, "slin_bwd: null pointer");
-    CHECK_ARG(M >= 1 && K >= 16 && K % 16 == 0 && N >= 16 && N % 16 == 0, "slin_bwd: M=%d K=%d N=%d (K, N multiples of 16)", M, K, N);
+    CHECK_ARG(M >= 1 && K >= 1 && N >= 1, "slin_bwd: M=%d K=%d N=%d", M, K, N);
     CHECK_ARG(Xn != nullptr || (xhat != nullptr && ln_g != nullptr && ln_b != nullptr) || (dW == nullptr), "slin_bwd: the weight gradient needs the GEMM input");
     CHECK_ARG(dX != nullptr || dW != nullptr || db != nullptr, "slin_bwd: nothing to compute");
     const int ktiles = (K + 63) / 64, mtiles = (M + 15) / 16;
     const int wktiles = dW != nullptr ? ktiles : 1;
-    SlinBwdArgs a{dY, Ymask, Xn, xhat, ln_g, ln_b, W, dX, dW, db, M, K, N, dX != nullptr ? mtiles * ktiles : 0, ktiles, wktiles};
+    // long reductions over n (G.linear: N = 24576; the stacked ccbn linears: 12096) are cut into ranges of 512 columns whose partial
+    // dX tiles are added with float atomics -- the caller passes a ZEROED dX then (dx_zeroed)
+    int nsplit = 1, nchunk = (N + 15) & ~15;
+    if (dX != nullptr && dx_zeroed && N % 16 == 0 && N >= 2048) {
+        nchunk = 512;
+        nsplit = (N + nchunk - 1) / nchunk;
+    }
+    SlinBwdArgs a{dY, Ymask, Xn, xhat, ln_g, ln_b, W, dX, dW, db, M, K, N, dX != nullptr ? mtiles * ktiles * nsplit : 0, ktiles, wktiles, nsplit, nchunk};
     const int nbw = (dW != nullptr || db != nullptr) ? ((N + 63) / 64) * wktiles : 0;
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof("slin_bwd", 2.0 * M * (double)K * N * ((dX ? 1 : 0) + (dW ? 1 : 0)), 4.0 * ((double)M * K + 2.0 * N * K + (double)M * N), st);
@@ -308,13 +355,58 @@ extern "C" int ieagan_ln_fwd(const float* X, const float* g, const float* b, flo
     return 0;
 }
 
-extern "C" int ieagan_ln_bwd(const float* dY, const float* xhat, const float* rstd, const float* g, const float* dRes, float* dX, float* dg, float* dbeta,
-                             int M, int K, void* stream) {
+extern "C" int ieagan_ln_bwd(const float* dY, const float* xhat, const float* rstd, const float* g, const float* l2_beta, const float* dRes, float* dX,
+                             float* dg, float* dbeta, int M, int K, void* stream) {
     CHECK_ARG(dY != nullptr && xhat != nullptr && rstd != nullptr && g != nullptr && dX != nullptr && M >= 1 && K >= 1, "ln_bwd: bad arguments");
     CHECK_ARG((dg == nullptr) == (dbeta == nullptr), "ln_bwd: d gamma / d beta come together");
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof("ln_bwd", 0.0, 16.0 * M * K, st);
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(M), dim3(256), 0, st, dY, xhat, rstd, g, dRes, dX, dg, dbeta, K);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(M), dim3(256), 0, st, dY, xhat, rstd, g, l2_beta, dRes, dX, dg, dbeta, K);
     CHECK_LAUNCH("ln_bwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Class proxies of the discriminator head: F.normalize(F.embedding(y, W / sigma), dim = 1) (reference model.py:916, 933); one block per row.
+// Backward: dW[y[m]] += (dp - p <dp, p>) / |w|, scattered with float atomics into the caller-zeroed [classes, D] gradient.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_norm_fwd_kernel(const long* __restrict__ y, const float* __restrict__ Wn, float* __restrict__ out,
+                                                              float* __restrict__ inv_out, int D) {
+    __shared__ float red[4];
+    const int m = blockIdx.x;
+    const float* row = Wn + y[m] * (long)D;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < D; c += 256) s += row[c] * row[c];
+    const float inv = 1.f / fmaxf(sqrtf(blk_sum(s, red)), 1e-12f);
+    for (int c = threadIdx.x; c < D; c += 256) out[(long)m * D + c] = row[c] * inv;
+    if (threadIdx.x == 0) inv_out[m] = inv;
+}
+
+__global__ __launch_bounds__(256) void embed_norm_bwd_kernel(const long* __restrict__ y, const float* __restrict__ p, const float* __restrict__ inv,
+                                                              const float* __restrict__ dp, float* __restrict__ dW, int D) {
+    __shared__ float red[4];
+    const int m = blockIdx.x;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < D; c += 256) s += dp[(long)m * D + c] * p[(long)m * D + c];
+    const float dot = blk_sum(s, red);
+    float* row = dW + y[m] * (long)D;
+    for (int c = threadIdx.x; c < D; c += 256) atomicAdd(row + c, (dp[(long)m * D + c] - p[(long)m * D + c] * dot) * inv[m]);
+}
+
+extern "C" int ieagan_embed_norm_fwd(const long* y, const float* Wn, float* out, float* inv, int M, int D, void* stream) {
+    CHECK_ARG(y != nullptr && Wn != nullptr && out != nullptr && inv != nullptr && M >= 1 && D >= 1, "embed_norm_fwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof("embed_norm_fwd", 0.0, 8.0 * M * D, st);
+    hipLaunchKernelGGL(embed_norm_fwd_kernel, dim3(M), dim3(256), 0, st, y, Wn, out, inv, D);
+    CHECK_LAUNCH("embed_norm_fwd");
+    return 0;
+}
+
+extern "C" int ieagan_embed_norm_bwd(const long* y, const float* p, const float* inv, const float* dp, float* dW, int M, int D, void* stream) {
+    CHECK_ARG(y != nullptr && p != nullptr && inv != nullptr && dp != nullptr && dW != nullptr && M >= 1 && D >= 1, "embed_norm_bwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof("embed_norm_bwd", 0.0, 12.0 * M * D, st);
+    hipLaunchKernelGGL(embed_norm_bwd_kernel, dim3(M), dim3(256), 0, st, y, p, inv, dp, dW, D);
+    CHECK_LAUNCH("embed_norm_bwd");
     return 0;
 }

@@ -125,6 +125,8 @@ class SNLinear(nn.Linear, SN):
         SN.__init__(self, num_svs, num_itrs, out_features, eps=eps)
 
     def fused(self, x, rec):
+        if x.is_cuda and x.dim() == 2 and self.in_features % 4 == 0 and self.in_features <= 2048:
+            return ops.LinearFn.apply(x, self.weight, self.bias, rec)       # one HIP launch each way (csrc/rrm_fused.hip)
         return F.linear(x, ops.SNWeightFn.apply(self.weight, rec), self.bias)
 
     def forward(self, x):

@@ -405,16 +405,19 @@ class Discriminator(nn.Module):
         h = ops.ReluSumPoolFn.apply(h)                                             # global sum pool of relu -> [N, C] fp32
         if self.conditional_strategy == "Contra":
             out = torch.squeeze(self.linear0.fused(h, recs["linear0"]))
-            proxy = self.embed.fused(y, recs["embed"])
+            nrm = self.normalize_embed
+            # unit-sphere class proxies: embedding lookup + F.normalize in one launch (model.py:916, 933)
+            proxy = ops.EmbedNormFn.apply(y, self.embed.weight, recs["embed"]) if nrm else self.embed.fused(y, recs["embed"])
             if self.RRM_embed:
                 N = h.shape[0]
                 E = _n_events(self, N)
                 h = self.RR_D(h.view(E, N // E, -1), recs=recs, prefix="RR_D").reshape(N, -1)
-                emb = self.norm(self.linear1.fused(h, recs["linear1"]))
+                # LayerNorm + F.normalize of the embedding in one launch (model.py:920-921, 935)
+                emb = ops.LayerNormFn.apply(self.linear1.fused(h, recs["linear1"]), self.norm.weight, self.norm.bias, self.norm.eps, nrm)
             else:
                 emb = self.linear1.fused(h, recs["linear1"])
-            if self.normalize_embed:
-                proxy, emb = F.normalize(proxy, dim=1), F.normalize(emb, dim=1)
+                if nrm:
+                    emb = F.normalize(emb, dim=1)
             return proxy, emb, out
         out = self.linear0.fused(h, recs["linear0"])
         return out + torch.sum(self.embed.fused(y, recs["embed"]) * h, 1, keepdim=True)

@@ -385,16 +385,16 @@ class StackedSNLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, wstack, recs, plan, *weights):
         ctx.recs, ctx.plan = recs, plan
+        y = y.contiguous()
         ctx.save_for_backward(y, wstack, *weights)
-        return y @ wstack.t()
+        return _slin_fwd(y, wstack, None, None)[0]
 
     @staticmethod
     def backward(ctx, g):
         y, wstack, *weights = ctx.saved_tensors
         plan, recs = ctx.plan, ctx.recs
         bank, ar = plan["bank"], plan["arena"]
-        dy = g @ wstack
-        gst = (g.t() @ y).contiguous()                    # [sum C, cond] gradient w.r.t. the normalised rows
+        dy, gst, _ = _slin_bwd(g.contiguous(), wstack, xn=y, want_db=False)     # gst: [sum C, cond] gradient w.r.t. the normalised rows
         direct = DIRECT_GRADS and ar.grads_attached()
         if direct:
             base, dst, out = ar.grad, plan["stack_dst_arena"], [None] * len(weights)
@@ -1152,28 +1152,34 @@ def _slin_fwd(x, w, b, res, ln_w=None, ln_b=None, relu=False, eps=1e-5):
 
 
 def _slin_bwd(dy, w, xn=None, xhat=None, ln_w=None, ln_b=None, ymask=None, want_dx=True, want_dw=True, want_db=True):
+    return _slin_bwd_impl(dy, w, xn, xhat, ln_w, ln_b, ymask, want_dx, want_dw, want_db)
+
+
+def _slin_bwd_impl(dy, w, xn, xhat, ln_w, ln_b, ymask, want_dx, want_dw, want_db):
     """(dx, dw, db) of one linear layer in one launch: dx = dy' w, dw = dy'^T xn, db = column sums of dy' (dy' = dy masked where
     ``ymask`` <= 0; xn = the GEMM input, or xhat * ln_w + ln_b)."""
     M, N = dy.shape
     K = w.shape[1]
     dev = dy.device
-    dx = torch.empty(M, K, dtype=torch.float32, device=dev) if want_dx else None
+    split = want_dx and N >= 2048 and N % 16 == 0          # long reduction over n: partial tiles are added into a zeroed dx
+    dx = (zeros((M, K), dev) if split else torch.empty(M, K, dtype=torch.float32, device=dev)) if want_dx else None
     dw = torch.empty(N, K, dtype=torch.float32, device=dev) if want_dw else None
     db = torch.empty(N, dtype=torch.float32, device=dev) if want_db else None
     if dx is None and dw is None and db is None:
         return None, None, None
     H.call("ieagan_slin_bwd", dy.data_ptr(), H.ptr(ymask), H.ptr(xn), H.ptr(xhat), H.ptr(ln_w), H.ptr(ln_b), w.data_ptr(), H.ptr(dx), H.ptr(dw),
-           H.ptr(db), M, K, N, H.stream())
+           H.ptr(db), M, K, N, int(split), H.stream())
     return dx, dw, db
 
 
-def _ln_bwd(dy, xhat, rstd, w, dres=None, want_param=True):
+def _ln_bwd(dy, xhat, rstd, w, dres=None, want_param=True, l2_beta=None):
+    """LayerNorm backward (+ the residual-path gradient ``dres``); ``l2_beta``: the forward ended with F.normalize."""
     M, K = dy.shape
     dx = torch.empty_like(dy)
     dg = zeros((K,), dy.device) if want_param else None
     dbeta = zeros((K,), dy.device) if want_param else None
-    H.call("ieagan_ln_bwd", dy.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), w.data_ptr(), H.ptr(dres), dx.data_ptr(), H.ptr(dg), H.ptr(dbeta), M, K,
-           H.stream())
+    H.call("ieagan_ln_bwd", dy.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), w.data_ptr(), H.ptr(l2_beta), H.ptr(dres), dx.data_ptr(), H.ptr(dg),
+           H.ptr(dbeta), M, K, H.stream())
     return dx, dg, dbeta
 
 
@@ -1192,20 +1198,66 @@ class LayerNormFn(torch.autograd.Function):
         H.call("ieagan_ln_fwd", x2.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), M, K, float(eps),
                int(l2norm), H.stream())
         ctx.shape, ctx.l2norm = shape, l2norm
-        ctx.save_for_backward(xhat, rstd, w, b, y if l2norm else None)
+        ctx.save_for_backward(xhat, rstd, w, b)
         return y.view(shape)
 
     @staticmethod
     def backward(ctx, dy):
-        xhat, rstd, w, b, y = ctx.saved_tensors
+        xhat, rstd, w, b = ctx.saved_tensors
         g = dy.reshape(-1, ctx.shape[-1]).contiguous().float()
-        if ctx.l2norm:          # y = u / |u|:  du = (dy - y <dy, y>) / |u|, with |u| recovered from u = xhat * w + b
-            u = xhat * w + b
-            nrm = u.norm(dim=1, keepdim=True).clamp_min(1e-12)
-            g = (g - y * (g * y).sum(1, keepdim=True)) / nrm
         need = ctx.needs_input_grad
-        dx, dg, dbeta = _ln_bwd(g, xhat, rstd, w, None, need[1] or need[2])
+        dx, dg, dbeta = _ln_bwd(g, xhat, rstd, w, None, need[1] or need[2], b if ctx.l2norm else None)
         return dx.view(ctx.shape), dg, dbeta, None, None
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b for a small fp32 linear layer (nn.Linear / SNLinear of the G entry and the D head, reference model.py:467, 475,
+    915, 920) in one launch each way; ``rec``: the layer's SNRecord (the GEMM then takes W / sigma of this pass and the weight
+    gradient goes through the spectral-norm backward) or None."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, rec):
+        w_eff = weight if rec is None else rec.w_plain.view(weight.shape)
+        x2 = x.contiguous().float()
+        y, _, _ = _slin_fwd(x2, w_eff, bias, None)
+        ctx.rec = rec
+        ctx.save_for_backward(x2, w_eff, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, w_eff, weight = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        dx, dw, db = _slin_bwd(g.contiguous().float(), w_eff, xn=x2, want_dx=need[0], want_dw=need[1], want_db=need[2])
+        if dw is not None and ctx.rec is not None:
+            dw = sn_backward(dw, weight, ctx.rec)[0]
+        return dx, dw, db, None
+
+
+class EmbedNormFn(torch.autograd.Function):
+    """F.normalize(SNEmbedding(y), dim=1): the unit-sphere class proxies of the discriminator head (model.py:916, 933)."""
+
+    @staticmethod
+    def forward(ctx, idx, weight, rec):
+        wn = rec.w_plain.view(weight.shape)
+        M, D = idx.numel(), weight.shape[1]
+        idx = idx.contiguous().long()
+        out = torch.empty(M, D, dtype=torch.float32, device=weight.device)
+        inv = torch.empty(M, dtype=torch.float32, device=weight.device)
+        H.call("ieagan_embed_norm_fwd", idx.data_ptr(), wn.data_ptr(), out.data_ptr(), inv.data_ptr(), M, D, H.stream())
+        ctx.rec = rec
+        ctx.save_for_backward(idx, out, inv, weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, dp):
+        idx, out, inv, weight = ctx.saved_tensors
+        if not ctx.needs_input_grad[1]:
+            return None, None, None
+        gsn = zeros(tuple(weight.shape), weight.device)
+        H.call("ieagan_embed_norm_bwd", idx.data_ptr(), out.data_ptr(), inv.data_ptr(), dp.contiguous().float().data_ptr(), gsn.data_ptr(),
+               idx.numel(), weight.shape[1], H.stream())
+        return None, sn_backward(gsn, weight, ctx.rec)[0], None
 
 
 class RRMBlockFn(torch.autograd.Function):

@@ -228,15 +228,20 @@ int ieagan_rrm_attention_bwd(const float* qkv, const float* att, const float* do
  *   slin_fwd:  Y[M,N] = [relu]( LN?(X)[M,K] W[N,K]^T + b ) [+ R]     LN: rows of X normalised with gamma / beta (eps), xhat [M,K] / rstd [M] saved
  *   slin_bwd:  dY' = dY masked where Ymask <= 0;  dX[M,K] = dY' W,  dW[N,K] = dY'^T Xn,  db[N] = column sums of dY'   (Xn NULL: xhat*ln_g+ln_b)
  *   ln_fwd:    nn.LayerNorm rows (+ F.normalize(., dim=1) with l2norm);   ln_bwd: its backward + dRes (residual path), dg / dbeta accumulated
- * K, N multiples of 16. */
+ * K a multiple of 4 (<= 2048 forward); dx_zeroed: dX is pre-zeroed, long reductions over n may then be split and added atomically;
+ * l2_beta: the LayerNorm was followed by F.normalize -- dY is the gradient w.r.t. the normalised rows. */
 int ieagan_slin_fwd(const float* X, const float* W, const float* b, const float* R, float* Y, const float* ln_g, const float* ln_b,
                     float* xhat, float* rstd, int M, int K, int N, int relu, float eps, void* stream);
 int ieagan_slin_bwd(const float* dY, const float* Ymask, const float* Xn, const float* xhat, const float* ln_g, const float* ln_b,
-                    const float* W, float* dX, float* dW, float* db, int M, int K, int N, void* stream);
+                    const float* W, float* dX, float* dW, float* db, int M, int K, int N, int dx_zeroed, void* stream);
 int ieagan_ln_fwd(const float* X, const float* g, const float* b, float* Y, float* xhat, float* rstd, int M, int K, float eps, int l2norm,
                   void* stream);
-int ieagan_ln_bwd(const float* dY, const float* xhat, const float* rstd, const float* g, const float* dRes, float* dX, float* dg, float* dbeta,
-                  int M, int K, void* stream);
+int ieagan_ln_bwd(const float* dY, const float* xhat, const float* rstd, const float* g, const float* l2_beta, const float* dRes, float* dX,
+                  float* dg, float* dbeta, int M, int K, void* stream);
+/* class proxies of the discriminator head: F.normalize(F.embedding(y, Wn), dim=1) (model.py:916, 933) and the scatter of its gradient
+ * into the caller-zeroed dW [classes, D] */
+int ieagan_embed_norm_fwd(const long* y, const float* Wn, float* out, float* inv, int M, int D, void* stream);
+int ieagan_embed_norm_bwd(const long* y, const float* p, const float* inv, const float* dp, float* dW, int M, int D, void* stream);
 /* all losses of one phase, value and gradient, one launch (loss.py:8-44, 79-132); weights6 (host) = weights of
  * {hinge_real, hinge_fake, hinge_gen, contrastive, uniformity, IEA}; vals8 (device) = {total, the six terms, 0} */
 int ieagan_loss_block(const float* dfake, const float* dreal, const float* e, const float* p, const float* er,
