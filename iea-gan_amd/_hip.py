@@ -13,6 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libieagan_hip.so")
+CONV_FP8_NOSCALE = 8     # with CONV_FP8 (benchmarks): the non-scaled K = 32 fp8 MFMA
 CONV_FP8 = 4             # ieagan_conv_desc.flags bit: e4m3 MFMA operands in the forward C = 64 / 128 3x3 launches (configs[4])
 CONV_NO_LDS_WEIGHTS = 2  # ieagan_conv_desc.flags bit: C = 64 / 128 3x3 layers through conv3x3_halo instead of conv3x3_lds
 CONV_FORCE_GATHER = 1   # ieagan_conv_desc.flags bit (tests): route a 3x3 layer through the gather kernel

@@ -258,8 +258,14 @@ static int lds_launch(const ConvArgs& a, hipStream_t st) {
 //     so one block's staging / epilogue runs under the other's MFMAs (the bf16 image of the same tile shape does not fit twice).
 //   * a lane's 16-byte chunk = 16 consecutive k of its row = the operands of TWO MFMAs (k order inside a 64-wide pair is a free
 //     choice as long as both operands agree).
-// HBM tensors stay bf16: only the operand precision of the forward MFMAs changes; dgrad / wgrad use the bf16 kernels.
+//   * MX = true (default): the block-scaled form v_mfma_scale_f32_16x16x128_f8f6f4 with all E8M0 block scales = 1 (the per-slice /
+//     per-tile fp32 scales above carry the range): one instruction consumes 128 k = the two 16-byte chunks a lane holds for two
+//     consecutive 64-k pairs, at TWICE the bf16 MFMA rate (the non-scaled K = 32 form runs at the bf16 rate on gfx950).  K = 9 * 64
+//     leaves one 64-k pair over, which takes the non-scaled instruction.
+//   * forward AND dgrad launches (ReLU-mask and BatchNorm-backward epilogues included); the weight gradients stay bf16.
+// HBM tensors stay bf16: only the operand precision of the MFMAs changes.
 // ------------------------------------------------------------------------------------------------------------------------
+typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef long i64;
 
 __device__ __forceinline__ i64 pack_fp8x8(const float (&v)[8], float scale) {
@@ -285,7 +291,7 @@ __device__ __forceinline__ float block_max(float v, float* scratch /*[NW]*/) {
     return m;
 }
 
-template <bool AFF, bool RELU, int RS, int CIN, int NT, int TH, int TW, int NW>
+template <bool AFF, bool RELU, int RS, int CIN, int NT, int TH, int TW, int NW, bool BNB, bool MX>
 __global__ __launch_bounds__(NW * 64, 2) void conv3x3_lds_fp8_kernel(ConvArgs a, int tiles_w, int tiles_h, int tpe, int tpb, int nblk, int bpe) {
     constexpr int AW = TW + 2, AH = TH + 2;
     constexpr int K = 9 * CIN;
@@ -465,6 +471,73 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_lds_fp8_kernel(ConvArgs a,
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) b[nt] = *(const F2*)(wsm + offB[kp % NVB] + nt * 16 * WCH * 16 + (kp / NVB) * NVB * 64);
         };
+        if constexpr (MX) {
+            // block-scaled form: one instruction per 128 k = the two 16-byte chunks a lane holds for two consecutive k pairs.
+            // DB (small register tiles, C = 128): fragments one step ahead in software; otherwise (C = 64: 16 accumulator tiles) the
+            // two resident blocks per CU cover each other's LDS latency -- a second fragment buffer would spill.
+            constexpr int KQ = KP / 2;
+            constexpr int ONE = 0x7F7F7F7F;           // E8M0 1.0 in every scale byte
+            constexpr bool DB = MTW * NT <= 4;
+            constexpr int NB = DB ? 2 : 1;
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
+            auto lda2 = [&](int q, i32x8(&x)[MTW]) {
+                const int k0 = 2 * q, k1 = 2 * q + 1;
+                const int tap0 = (k0 * 64) / CIN, cq0 = ((k0 * 64) % CIN) / 64, tap1 = (k1 * 64) / CIN, cq1 = ((k1 * 64) % CIN) / 64;
+                const int imm0 = ((tap0 / 3) * AW + (tap0 % 3)) * CH * 16, imm1 = ((tap1 / 3) * AW + (tap1 % 3)) * CH * 16;
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) {
+                    const i32x4 lo = *(const i32x4*)(hsm + offA[m][tap0 % 3][cq0] + imm0);
+                    const i32x4 hi = *(const i32x4*)(hsm + offA[m][tap1 % 3][cq1] + imm1);
+                    x[m] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+            };
+            auto ldb2 = [&](int q, i32x8(&b)[NT]) {
+                const int k0 = 2 * q, k1 = 2 * q + 1;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const i32x4 lo = *(const i32x4*)(wsm + offB[k0 % NVB] + nt * 16 * WCH * 16 + (k0 / NVB) * NVB * 64);
+                    const i32x4 hi = *(const i32x4*)(wsm + offB[k1 % NVB] + nt * 16 * WCH * 16 + (k1 / NVB) * NVB * 64);
+                    b[nt] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+            };
+            i32x8 aq[NB][MTW], bq[NB][NT];
+            if (DB) {
+                lda2(0, aq[0]);
+                ldb2(0, bq[0]);
+            }
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) {
+                if (DB) {
+                    if (q + 1 < KQ) {
+                        lda2(q + 1, aq[(q + 1) & 1]);
+                        ldb2(q + 1, bq[(q + 1) & 1]);
+                    }
+                } else {
+                    lda2(q, aq[0]);
+                    ldb2(q, bq[0]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[m][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(aq[DB ? (q & 1) : 0][m], bq[DB ? (q & 1) : 0][nt], acc[m][nt], 0, 0, 0, ONE,
+                                                                                      0, ONE);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (KP & 1) {                             // the left-over 64-k pair (K = 9 * 64): the non-scaled instruction
+                F2 ta[MTW], tb[NT];
+                lda(KP - 1, ta);
+                ldb(KP - 1, tb);
+#pragma unroll
+                for (int m = 0; m < MTW; ++m)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(ta[m].lo, tb[nt].lo, acc[m][nt], 0, 0, 0);
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(ta[m].hi, tb[nt].hi, acc[m][nt], 0, 0, 0);
+                    }
+            }
+        } else {
         F2 aq[2][MTW], bq[2][NT];
         lda(0, aq[0]);
         ldb(0, bq[0]);
@@ -483,6 +556,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_lds_fp8_kernel(ConvArgs a,
                     acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(aq[kp & 1][m].hi, bq[kp & 1][nt].hi, acc[m][nt], 0, 0, 0);
                 }
             __builtin_amdgcn_sched_barrier(0);
+        }
         }
         const float inv = inv_sw * inv_sa;
 #pragma unroll
@@ -505,7 +579,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_lds_fp8_kernel(ConvArgs a,
                 return h < H && w < W;
             };
             const f32x4(&sub)[2][NT] = *reinterpret_cast<const f32x4(*)[2][NT]>(&acc[2 * half]);
-            conv_epilogue<false, NT, 2, false>(a, sub, epi, n_base, pix, s1, s2);
+            conv_epilogue<BNB, NT, 2, false>(a, sub, epi, n_base, pix, s1, s2);
         }
     }
     if (a.stats != nullptr) {
@@ -514,7 +588,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_lds_fp8_kernel(ConvArgs a,
     }
 }
 
-template <bool AFF, bool RELU, int RS>
+template <bool AFF, bool RELU, int RS, bool BNB = false>
 static int lds_fp8_launch(const ConvArgs& a, hipStream_t st) {
     const int n_events = (a.stats != nullptr && a.n_per_event > 0) ? a.N / a.n_per_event : 1;
 #define F8_LAUNCH(CINV, NTV, THV, TWV, NWV)                                                                                        \
@@ -530,8 +604,12 @@ static int lds_fp8_launch(const ConvArgs& a, hipStream_t st) {
         const int nblk = bpe * n_events;                                                                                           \
         const size_t halo = (size_t)(THV + 2) * (TWV + 2) * CINV, epi = (size_t)NWV * EpiLds<NTV>::FLOATS * 4;                     \
         const size_t lds = (size_t)NTV * 16 * 9 * CINV + (halo > epi ? halo : epi);                                                \
-        hipLaunchKernelGGL((conv3x3_lds_fp8_kernel<AFF, RELU, RS, CINV, NTV, THV, TWV, NWV>), dim3(nblk, gy), dim3(NWV * 64), lds, \
-                           st, a, tiles_w, tiles_h, tpe, tpb, nblk, bpe);                                                          \
+        if (a.flags & IEAGAN_CONV_FP8_NOSCALE)                                                                                     \
+            hipLaunchKernelGGL((conv3x3_lds_fp8_kernel<AFF, RELU, RS, CINV, NTV, THV, TWV, NWV, BNB, false>), dim3(nblk, gy), dim3(NWV * 64), lds, \
+                               st, a, tiles_w, tiles_h, tpe, tpb, nblk, bpe);                                                      \
+        else                                                                                                                       \
+            hipLaunchKernelGGL((conv3x3_lds_fp8_kernel<AFF, RELU, RS, CINV, NTV, THV, TWV, NWV, BNB, true>), dim3(nblk, gy), dim3(NWV * 64), lds, \
+                               st, a, tiles_w, tiles_h, tpe, tpb, nblk, bpe);                                                      \
         return 1;                                                                                                                  \
     }
     if (a.Cin == 64 && a.Cout % 64 == 0 && a.H >= 8 && a.W >= 32) F8_LAUNCH(64, 4, 8, 32, 4)
@@ -545,9 +623,10 @@ int conv3x3_lds_launch(const ConvArgs& a, hipStream_t st) {
     if (a.taps != 9 || (a.src.rs != 0 && a.src.rs != 1) || a.Kpad != 9 * a.Cin || (a.Cin != 64 && a.Cin != 128)) return 0;
     if (a.src.scale != nullptr && a.Cin > AFF_MAXC) return 0;
     const bool aff = a.src.scale != nullptr, relu = a.src.relu != 0;
-    if ((a.flags & IEAGAN_CONV_FP8) && a.bnb_scale == nullptr && a.mask == nullptr) {      // forward launches only
+    if (a.flags & IEAGAN_CONV_FP8) {          // forward launches and dgrad launches (plain prologue + ReLU-mask / BatchNorm-backward epilogue)
         int r = 0;
-        if (a.src.rs == 0) r = aff ? (relu ? lds_fp8_launch<true, true, 0>(a, st) : lds_fp8_launch<true, false, 0>(a, st))
+        if (a.bnb_scale != nullptr) r = (a.src.rs == 0 && !aff && !relu) ? lds_fp8_launch<false, false, 0, true>(a, st) : 0;
+        else if (a.src.rs == 0) r = aff ? (relu ? lds_fp8_launch<true, true, 0>(a, st) : lds_fp8_launch<true, false, 0>(a, st))
                                    : (relu ? lds_fp8_launch<false, true, 0>(a, st) : lds_fp8_launch<false, false, 0>(a, st));
         else r = aff ? (relu ? lds_fp8_launch<true, true, 1>(a, st) : lds_fp8_launch<true, false, 1>(a, st))
                      : (relu ? lds_fp8_launch<false, true, 1>(a, st) : lds_fp8_launch<false, false, 1>(a, st));

@@ -538,7 +538,7 @@ static int launch_halo_pro(const ConvArgs& a, hipStream_t st) {
 
 int conv_gather_launch(const ConvArgs& a, hipStream_t st) {
     CHECK_ARG(a.taps == 1 || a.taps == 9, "conv: taps must be 1 or 9 (got %d)", a.taps);
-    CHECK_ARG((a.flags & ~(IEAGAN_CONV_FORCE_GATHER | IEAGAN_CONV_NO_LDS_WEIGHTS | IEAGAN_CONV_FP8)) == 0, "conv: unknown flag bits 0x%x", a.flags);
+    CHECK_ARG((a.flags & ~(IEAGAN_CONV_FORCE_GATHER | IEAGAN_CONV_NO_LDS_WEIGHTS | IEAGAN_CONV_FP8 | IEAGAN_CONV_FP8_NOSCALE)) == 0, "conv: unknown flag bits 0x%x", a.flags);
     CHECK_ARG(a.Cin % 8 == 0 && a.Cout % 8 == 0, "conv: Cin/Cout must be multiples of 8 (%d,%d)", a.Cin, a.Cout);
     CHECK_ARG(a.Kpad % 32 == 0 && a.Kpad >= a.taps * a.Cin, "conv: bad Kpad %d", a.Kpad);
     CHECK_ARG(a.src.rs >= 0 && a.src.rs <= 2, "conv: bad resample mode %d", a.src.rs);

@@ -104,9 +104,11 @@ class SNConv2d(nn.Conv2d, SN):
         else:
             self._sn_kind = ops.KIND_CONV
 
+    conv_flags = 0          # ieagan_conv_desc.flags of this layer; set by the owning network (conv_dtype='fp8' -> H.CONV_FP8)
+
     # fused internal entry (bf16 NHWC in/out); kwargs are those of ops.conv
     def fused(self, xa, rec, **kw):
-        return ops.conv(xa, self.weight, self.bias, rec, self.taps, **kw)
+        return ops.conv(xa, self.weight, self.bias, rec, self.taps, flags=self.conv_flags, **kw)
 
     def forward(self, x):
         rec = self._record()

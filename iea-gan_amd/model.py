@@ -69,6 +69,18 @@ def _activation(name):
     raise NotImplementedError(f"activation function {name} not implemented on the MI355X path (ReLU is fused into the convs)")
 
 
+def _set_conv_dtype(net, conv_dtype):
+    """``conv_dtype`` of a network ('bf16' | 'fp8', BASELINE configs[4]): the operand precision of the MFMAs of its C = 64 / 128 3x3
+    layers, carried per layer in the conv descriptor flags (no process-wide switch: two networks / train functions with different
+    settings coexist)."""
+    if conv_dtype not in ("bf16", "fp8"):
+        raise NotImplementedError("conv_dtype must be 'bf16' or 'fp8'")
+    net.conv_dtype = conv_dtype
+    for m in net.modules():
+        if isinstance(m, layers.SNConv2d):
+            m.conv_flags = H.CONV_FP8 if conv_dtype == "fp8" else 0
+
+
 def _n_events(net, n_images):
     """Number of independent events in a batch of ``n_images``: ``events_per_step`` when the batch is exactly that many
     events of ``event_size`` images, else 1 (the whole batch is one event, as in the reference)."""
@@ -193,6 +205,7 @@ class Generator(nn.Module):
         c_last = self.arch["out_channels"][-1]
         self.output_layer = nn.Sequential(layers.bn(c_last, cross_replica=cross_replica, mybn=mybn), self.activation,
                                           self.which_conv(c_last, 1))
+        _set_conv_dtype(self, kwargs.get("conv_dtype", "bf16"))
         if not skip_init:
             self.init_weights()
         self._plan = None
@@ -365,6 +378,7 @@ class Discriminator(nn.Module):
             self.embed = self.which_embedding(n_classes, hypersphere_dim)
         else:
             raise NotImplementedError(f"conditional_strategy {conditional_strategy}")
+        _set_conv_dtype(self, kwargs.get("conv_dtype", "bf16"))
         if not skip_init:
             self.init_weights()
         self._plan = None

@@ -527,7 +527,6 @@ def _conv_launch(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu, N, Hc, Wc, Cin,
 
 
 USE_TR_READ = True        # ds_read_b64_tr_b16 operand reads in conv_wgrad (False: scalar LDS reads)
-FP8_FORWARD = False       # forward MFMA operands of the C = 64 / 128 3x3 layers in OCP e4m3 (config conv_dtype='fp8', BASELINE configs[4])
 TWO_STAGE_WGRAD = True    # conv_wgrad: partial slabs + reduction launch instead of float atomics when the atomic volume is large
 # Weight-gradient launches of a training backward pass go to a side stream: nothing in the pass reads dW before the batched
 # spectral-norm backward at its end (SNPass.flush joins), so they run under the dgrad chain of this and the following layers --
@@ -726,12 +725,12 @@ def _conv1x1_backward_fused(ctx, dout, dstats):
         res_in.deposit(dx, Cin, Cin, 2)
         dx = None
     dW, dbias = sn_backward(dwp, weight, rec, colsum, ctx.bias_ref)
-    return dx, dW, dbias, dscale, dshift, d_ra, d_rb, None, None, None, None, None, None, None, None, None, None
+    return dx, dW, dbias, dscale, dshift, d_ra, d_rb, None, None, None, None, None, None, None, None, None, None, None
 
 
 class ConvFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, scale, shift, ra, rb, rec, taps, rs, relu, Ca, ra_rs, want_stats, res_out, res_in, events=1):
+    def forward(ctx, x, weight, bias, scale, shift, ra, rb, rec, taps, rs, relu, Ca, ra_rs, want_stats, res_out, res_in, events=1, flags=0):
         N, Hs, Ws, Cx = x.shape
         Cout, Cin = rec.out, rec.cin
         assert x.dtype == BF16 and x.is_contiguous() and Cx == Cin, (x.dtype, x.shape, Cin)
@@ -740,11 +739,13 @@ class ConvFn(torch.autograd.Function):
         out = torch.empty(N, Hc, Wc, Cout, dtype=BF16, device=x.device)
         stats = new_stats(Cout, x.device, events) if want_stats else None
         nstride = 0 if (scale is None or scale.dim() == 1) else scale.shape[1]
-        flags = H.CONV_FP8 if (FP8_FORWARD and taps == 9 and Cin in (64, 128)) else 0
+        # per-layer kernel-selection flags of the conv descriptor (H.CONV_FP8: e4m3 MFMA operands, conv_dtype='fp8' of the owning
+        # network -- BASELINE configs[4]); they only mean something to the C = 64 / 128 3x3 kernels and ride along to the dgrad launch
+        flags = int(flags) if (taps == 9 and Cin in (64, 128)) else 0
         _conv_launch(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu, N, Hc, Wc, Cin, Cout, taps, rec.kpad, rec.w_fwd,
                      bias, ra, ra.shape[-1] if ra is not None else 0, Ca, ra_rs, rb,
                      rb.shape[-1] if rb is not None else 0, None, out, stats, npe=N // events, flags=flags)
-        ctx.events = events
+        ctx.events, ctx.flags = events, flags
         ctx.rec, ctx.cfg = rec, (taps, rs, relu, Ca, ra_rs, nstride, Hc, Wc)
         ctx.ra_shape = ra.shape if ra is not None else None
         ctx.has = (bias is not None, scale is not None, ra is not None, rb is not None)
@@ -841,7 +842,7 @@ class ConvFn(torch.autograd.Function):
                 up = res_in is not None and lmode == 1          # shortcut gradient at double resolution: 2x2 SUM = 4 * average
                 _conv_launch(g, Cg, Hc, Wc, 0, None, None, 0, False, N, Hc, Wc, Cout, Cin, taps, rec.kpad2, rec.w_bwd, None,
                              lg, lC or 0, lCa or 0, 2 if up else 0, None, 0, x, dx, acc, ra_scale=4.0 if up else 1.0, npe=1,
-                             bnb=(scale, shift, nstride, relu))
+                             bnb=(scale, shift, nstride, relu), flags=ctx.flags)
                 bn_link.acc = acc
                 dscale = dshift = _placeholder(scale)
             elif res_in is not None and (fuse_mask or (plain and rs == 0)):
@@ -849,7 +850,7 @@ class ConvFn(torch.autograd.Function):
                 # shortcut gradient (0.25 * nearest-expand when the shortcut was average-pooled)
                 _conv_launch(g, Cg, Hc, Wc, 0, None, None, 0, False, N, Hc, Wc, Cout, Cin, taps, rec.kpad2, rec.w_bwd, None,
                              lg, lC, lCa, 1 if lmode == 2 else 0, None, 0, x if fuse_mask else None, da, None,
-                             ra_scale=0.25 if lmode == 2 else 1.0)
+                             ra_scale=0.25 if lmode == 2 else 1.0, flags=ctx.flags)
                 dx = da
             elif res_in is not None and plain and rs == 2 and res_out is None:
                 # conv_sc of a D block (pooled, un-activated input): chain -- add the deposited shortcut
@@ -860,7 +861,7 @@ class ConvFn(torch.autograd.Function):
                 dx = None
             else:
                 _conv_launch(g, Cg, Hc, Wc, 0, None, None, 0, False, N, Hc, Wc, Cout, Cin, taps, rec.kpad2, rec.w_bwd, None,
-                             None, 0, 0, 0, None, 0, x if fuse_mask else None, da, None)
+                             None, 0, 0, 0, None, 0, x if fuse_mask else None, da, None, flags=ctx.flags)
                 if (fuse_mask or (plain and rs == 0)) and res_in is None:
                     dx = da
                 else:
@@ -910,14 +911,14 @@ class ConvFn(torch.autograd.Function):
             dW, dbias = sn_backward(dwp, weight, rec, colsum if (has_bias and need[2]) else None, ctx.bias_ref)
         elif has_bias and need[2]:
             dbias = colsum.sum(0)
-        return dx, dW, dbias, dscale, dshift, d_ra, d_rb, None, None, None, None, None, None, None, None, None, None
+        return dx, dW, dbias, dscale, dshift, d_ra, d_rb, None, None, None, None, None, None, None, None, None, None, None
 
 
 def conv(x, weight, bias, rec, taps, *, scale=None, shift=None, relu=False, rs=0, ra=None, Ca=0, ra_rs=0, rb=None,
-         want_stats=False, res_out=None, res_in=None, events=1):
+         want_stats=False, res_out=None, res_in=None, events=1, flags=0):
     """``events``: the batch holds that many events of N / events images each; the statistics of the output are taken per
-    event ([E, STAT_REPL, 2, Cout])."""
-    return ConvFn.apply(x, weight, bias, scale, shift, ra, rb, rec, taps, rs, relu, Ca, ra_rs, want_stats, res_out, res_in, events)
+    event ([E, STAT_REPL, 2, Cout]).  ``flags``: ieagan_conv_desc.flags of this layer (H.CONV_FP8)."""
+    return ConvFn.apply(x, weight, bias, scale, shift, ra, rb, rec, taps, rs, relu, Ca, ra_rs, want_stats, res_out, res_in, events, flags)
 
 
 # =====================================================================================================

@@ -106,7 +106,10 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
     bs = config["batch_size"]
     if config.get("conv_dtype", "bf16") not in ("bf16", "fp8"):
         raise NotImplementedError("conv_dtype must be 'bf16' or 'fp8'")
-    ops.FP8_FORWARD = config.get("conv_dtype", "bf16") == "fp8"      # process-wide operand precision of the forward convolutions
+    for net in (G, D):          # the operand precision is a property of the NETWORKS (per-layer descriptor flags), set at construction
+        if getattr(net, "conv_dtype", "bf16") != config.get("conv_dtype", "bf16"):
+            raise ValueError(f"config['conv_dtype'] = {config.get('conv_dtype', 'bf16')!r} but the network was built with "
+                             f"{getattr(net, 'conv_dtype', 'bf16')!r}: pass the same config to Generator / Discriminator")
     E = max(int(config.get("events_per_step", 1) or 1), 1)
     if E > 1 and not (config["split_D"] and config["num_D_accumulations"] == 1 and config["num_G_accumulations"] == 1):
         raise NotImplementedError("events_per_step > 1 needs split_D and no gradient accumulation: the E events of a step are "

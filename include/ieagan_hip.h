@@ -81,8 +81,10 @@ typedef struct {
     int bnb_relu;
 } ieagan_conv_desc;
 #define IEAGAN_CONV_FORCE_GATHER 1
-#define IEAGAN_CONV_FP8 4              /* forward launches of the C = 64 / 128 3x3 layers with OCP e4m3 MFMA operands (per-slice weight
-                                        * scale, per-tile activation scale, fp32 accumulate): BASELINE configs[4]; tensors stay bf16 */
+#define IEAGAN_CONV_FP8 4              /* forward and dgrad launches of the C = 64 / 128 3x3 layers with OCP e4m3 MFMA operands (per-slice
+                                        * weight scale, per-tile activation scale, block-scaled K = 128 MFMA, fp32 accumulate): BASELINE
+                                        * configs[4]; tensors stay bf16 */
+#define IEAGAN_CONV_FP8_NOSCALE 8      /* with IEAGAN_CONV_FP8 (benchmarks): the non-scaled K = 32 fp8 MFMA instead of the block-scaled K = 128 form */
 #define IEAGAN_CONV_NO_LDS_WEIGHTS 2   /* tests / benchmarks: C = 64 / 128 3x3 layers through conv3x3_halo instead of conv3x3_lds */
 int ieagan_conv_forward(const ieagan_conv_desc* d, void* stream);
 

@@ -55,9 +55,9 @@ def cosine(a, b):
     return float(torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-20))
 
 
-def forward_parity(resolution=64, H_base=1, device="cuda:0", n=40, seed=5, z=None, rdof=None):
+def forward_parity(resolution=64, H_base=1, device="cuda:0", n=40, seed=5, z=None, rdof=None, **cfg_over):
     """G(z,y) then D(G_z, y) in training mode: outputs + updated buffers vs the oracle."""
-    cfg = make_cfg(resolution=resolution, H_base=H_base, n_classes=max(n, 40))
+    cfg = make_cfg(resolution=resolution, H_base=H_base, n_classes=max(n, 40), **cfg_over)
     g_state, d_state = O.synth_nets(cfg, 101, 202)
     G, D = build_product(cfg, g_state, d_state, device)
     gen = torch.Generator().manual_seed(seed)

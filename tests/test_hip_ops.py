@@ -288,7 +288,7 @@ def test_fp8_forward_conv_vs_bf16_and_fp32(dev, N, Hh, Ww, C, aff):
     a = F.relu(a)
     ref = F.conv2d(a, w.float().view(C, 3, 3, C).permute(0, 3, 1, 2), bias, 1, 1)
     outs = {}
-    for name, flags in (("bf16", 0), ("fp8", _hip.CONV_FP8)):
+    for name, flags in (("bf16", 0), ("fp8", _hip.CONV_FP8), ("fp8_k32", _hip.CONV_FP8 | _hip.CONV_FP8_NOSCALE)):
         out = torch.empty(N, Hh, Ww, C, device=dev, dtype=BF)
         st = ops.new_stats(C, dev)
         ops._conv_launch(x, C, Hh, Ww, 0, sc, sh, C if aff else 0, True, N, Hh, Ww, C, C, 9, kpad, w, bias, None, 0, 0, 0, None, 0, None, out, st,
@@ -299,6 +299,10 @@ def test_fp8_forward_conv_vs_bf16_and_fp32(dev, N, Hh, Ww, C, aff):
     print(f"rel-L2 vs fp32: bf16 {e16:.2e}, fp8 {e8:.2e}")
     assert e16 <= 6e-3 and e8 <= 4e-2, (e16, e8)
     assert e8 > e16                                        # the fp8 path really ran with fp8 operands
+    # the block-scaled K = 128 instruction (all block scales 1) sums the SAME e4m3 products as four K = 32 instructions: only the
+    # fp32 accumulation order differs (a wrong k pairing of the two operands would be an O(1) error)
+    d = float((outs["fp8"][0] - outs["fp8_k32"][0]).norm() / outs["fp8_k32"][0].norm())
+    assert d <= 4e-3, d                                    # (outputs are bf16-rounded: a last-bit flip here and there)
     close(outs["fp8"][1][0], ref.sum((0, 2, 3)), 5e-2, "fp8 stat sum")
     close(outs["fp8"][1][1], (ref * ref).sum((0, 2, 3)), 5e-2, "fp8 stat sumsq")
 
@@ -874,3 +878,35 @@ def test_fused_1x1_backward_matches_separate_launches(dev, ref_cfg, kind, cin, c
             continue
         err = float((got - ref).norm() / ref.norm())
         assert err <= 1e-2, (k, err)
+
+
+@pytest.mark.parametrize("N,Hh,Ww,C,aff", [(8, 64, 192, 64, True), (6, 32, 96, 64, False), (4, 16, 48, 128, True), (3, 8, 24, 128, False)])
+def test_fp8_conv_dgrad_vs_fp32(dev, N, Hh, Ww, C, aff):
+    """conv_dtype='fp8' dgrad of the C = 64 / 128 3x3 layers (plain prologue; ReLU-mask epilogue for the D layers, BatchNorm-backward
+    epilogue for the G layers) through ops.conv's autograd: gradient w.r.t. the conv input against fp32 autograd of the same
+    composite -- rel-L2 <= 5e-2 (e4m3 operands: ~3 % per product), the bf16 path <= 1.5e-2 on the same operands."""
+    import _hip, ops
+    torch.manual_seed(41)
+    x = r16(torch.randn(N, C, Hh, Ww, device=dev)).requires_grad_(True)
+    W = (torch.randn(C, C, 3, 3, device=dev) / math.sqrt(9 * C)).requires_grad_(True)
+    u = torch.randn(1, C, device=dev)
+    bias = (0.1 * torch.randn(C, device=dev)).requires_grad_(True)
+    scale = (1 + 0.3 * torch.randn(N, C, device=dev)) if aff else None
+    shift = (0.2 * torch.randn(N, C, device=dev)) if aff else None
+    ref = conv_reference(x, W, u, bias, scale, shift, True, 0, 9, None, 0, 0, None)
+    go = r16(torch.randn_like(ref))
+    (gx_ref,) = torch.autograd.grad((ref * go).sum(), [x])
+    errs = {}
+    for name, flags in (("bf16", 0), ("fp8", _hip.CONV_FP8)):
+        rec, Wv, uv, svv = make_rec(W.detach(), u, torch.ones(1, device=dev))
+        xa = nhwc(x.detach()).requires_grad_(True)
+        sc2 = scale.clone().requires_grad_(True) if aff else None
+        sh2 = shift.clone().requires_grad_(True) if aff else None
+        if aff:
+            sc2._bn_link = ops.BNLink()              # dgrad with the BatchNorm-backward epilogue (per-image accumulators)
+        out, _ = ops.conv(xa, Wv.detach().requires_grad_(True), bias.detach().clone().requires_grad_(True), rec, 9, scale=sc2, shift=sh2,
+                          relu=True, flags=flags)
+        (gx,) = torch.autograd.grad((out.float() * nhwc(go).float()).sum(), [xa])
+        errs[name] = float((nchw(gx) - gx_ref).norm() / gx_ref.norm())
+    print(errs)
+    assert errs["bf16"] <= 1.5e-2 and errs["fp8"] <= 5e-2 and errs["fp8"] > errs["bf16"], errs

@@ -149,21 +149,28 @@ def test_train_step_joint_pass_and_projection_head(golden_dir, tag, over):
 
 
 def test_fp8_conv_path_forward_and_step_tolerance():
-    """BASELINE configs[4] (conv_dtype='fp8'): the C >= 64 3x3 forward launches take e4m3 MFMA operands; everything else
-    (tensors in HBM, dgrad / wgrad, statistics, spectral norm, losses) is unchanged.  Re-stated tolerance against the fp32 oracle at
-    40x64x64: G output rel-L2 <= 8e-2 (bf16 path: 5e-2), D logits <= 8e-2, embeddings <= 5e-2; step losses within 8 %, flat
-    gradient cosine >= 0.95."""
-    import ops
-    from parity_util import O, build_product, make_cfg
-    ops.FP8_FORWARD = True
-    try:
-        rep, _ = forward_parity(64, 1)
-        print(json.dumps(rep))
-        assert rep["G_rel_l2"] <= 8e-2 and rep["D_out_rel_l2"] <= 8e-2 and rep["D_embed_rel_l2"] <= 5e-2, rep
-    finally:
-        ops.FP8_FORWARD = False
+    """BASELINE configs[4] (conv_dtype='fp8'): the C >= 64 3x3 forward AND dgrad launches take e4m3 MFMA operands (block-scaled
+    K = 128 MFMA, per-slice / per-tile scales); everything else (tensors in HBM, weight gradients, statistics, spectral norm, losses)
+    is unchanged.  Re-stated tolerance against the fp32 oracle at 40x64x64: G output rel-L2 <= 8e-2 (bf16 path: 5e-2), D logits
+    <= 8e-2, embeddings <= 5e-2; step losses within 8 %, flat gradient cosine >= 0.95 (bf16: 0.97)."""
+    rep, _ = forward_parity(64, 1, conv_dtype="fp8")
+    print(json.dumps(rep))
+    assert rep["G_rel_l2"] <= 8e-2 and rep["D_out_rel_l2"] <= 8e-2 and rep["D_embed_rel_l2"] <= 5e-2, rep
     rep = step_parity(64, 1, conv_dtype="fp8")
-    ops.FP8_FORWARD = False
+    print(json.dumps(rep))
+    for k, v in rep["losses"].items():
+        ref = rep["ref_losses"][k]
+        assert abs(v - ref) <= 8e-2 * max(1.0, abs(ref)), (k, v, ref)
+    assert rep["G_grad_cos"] >= 0.95 and rep["D_grad_cos"] >= 0.95, rep
+    # two train functions with different conv_dtype coexist in one process (per-layer descriptor flags, no global switch)
+    rep16 = step_parity(64, 1)
+    assert rep16["ok"], rep16
+
+
+def test_fp8_conv_path_256x768_subevent_tolerance():
+    """The same statement at the benchmark geometry (8 sensors at 256x768: the C = 64 layers run at 64x192 / 32x96, C = 128 at
+    16x48 / 8x24 with the tile shapes of the 40-sensor step): losses within 8 %, gradient cosine >= 0.95 against the fp32 oracle."""
+    rep = step_parity(256, 3, n=8, conv_dtype="fp8")
     print(json.dumps(rep))
     for k, v in rep["losses"].items():
         ref = rep["ref_losses"][k]
