@@ -42,6 +42,7 @@ import torch.distributed as dist
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0         # HBM3E spec (6.3 TB/s measured achievable)
 STEP_GFLOP = 5328.8           # algorithmic work per event-step (SURVEY 8d / BASELINE.md section 3)
+BENCH_LR = 1e-7               # see bench_config(): keeps both hinge terms of D unsaturated over the timed steps
 PMC_FILES = ("r02_pmc_traffic.json", "r01_final_pmc_traffic.json")      # newest first
 
 
@@ -60,6 +61,12 @@ def bench_config(which=1):
     # clip_norm must be finite or the reference's control flow never steps G's optimiser -- a benchmark without
     # the G update would skip real work.
     cfg.update(device="cuda", clip_norm=1e9)
+    # Regime of the timed steps: both discriminator hinge terms must stay ACTIVE (relu(1 - D(x)) > 0 and relu(1 + D(G(z))) > 0), or one
+    # of the two full D backward passes propagates exact zeros (round-2 review).  A randomly initialised D puts every logit near -11 and
+    # the shipped lr of 5e-5 (Adam, beta1 = 0: every weight moves by ~lr per step) swings them through the margin within two steps, so
+    # the bench (i) centres the logits once with D.linear0.bias (measure(): calibrate) and (ii) trains with a learning rate small enough
+    # that 40 steps stay inside the margin.  Neither changes the arithmetic of a step: same launches, same bytes, same FLOPs.
+    cfg.update(G_lr=BENCH_LR, D_lr=BENCH_LR)
     if which == 1:      # configs[1]: hinge loss only, RRM on
         cfg.update(contra_lambda=0.0, IEA_loss=False, Uniformity_loss=False)
     elif which == 3:    # configs[3]: 4 events/GPU, diff_aug + cr_diff_aug + uniformity loss (full default loss composition)
@@ -189,6 +196,17 @@ def measure(cfg, args, rank, world, local, tag):
         G_ema = model.Generator(**dict(cfg, skip_init=True, no_optim=True)).to(dev)
         ema = utils.apply_ema(G, G_ema, cfg["ema_decay"], cfg["ema_start"])
     GD = model.G_D(G, D)
+    h, w = cfg["resolution"], cfg["resolution"] * cfg["H_base"]
+    n_rot = 4
+    xs = [torch.cat([synth_event(40, h, w, cfg["seed"] + 1000 * rank + 10 * i + e) for e in range(E)]).to(dev) for i in range(n_rot)]
+    y = torch.arange(40, device=dev).repeat(E)
+    # calibrate: centre the logits of this random initialisation between the two hinge margins (same on every rank: same seed)
+    G.train(); D.train()
+    with torch.no_grad():
+        zc = torch.randn(40 * E, G.dim_z, device=dev)
+        lf = D(G(zc, y), y)[2] if cfg["conditional_strategy"] == "Contra" else D(G(zc, y), y)
+        lr_ = D(xs[0], y)[2] if cfg["conditional_strategy"] == "Contra" else D(xs[0], y)
+        D.linear0.bias.sub_(0.5 * (lf.float().mean() + lr_.float().mean()))
     if world > 1 or force_dp:
         parallel.set_context(parallel.GradSync(overlap=True, force=force_dp))
         for net in (G, D):
@@ -198,10 +216,6 @@ def measure(cfg, args, rank, world, local, tag):
     z_, y_ = utils.prepare_z_y(40 * E, G.dim_z, cfg["n_classes"], device=dev)
     state = {"itr": 0}
     train = train_fns.GAN_training_function(G, D, GD, z_, y_, ema, state, cfg, dev)
-    h, w = cfg["resolution"], cfg["resolution"] * cfg["H_base"]
-    n_rot = 4
-    xs = [torch.cat([synth_event(40, h, w, cfg["seed"] + 1000 * rank + 10 * i + e) for e in range(E)]).to(dev) for i in range(n_rot)]
-    y = torch.arange(40, device=dev).repeat(E)
     G.train(); D.train(); G_ema.train()
 
     trace = []
@@ -333,6 +347,7 @@ def main():
     ap.add_argument("--shape-tags", action="store_true", help="per-kernel timing split by layer shape (tuning aid)")
     ap.add_argument("--trace-losses", action="store_true", help="print the losses of every step to stderr (tuning aid)")
     ap.add_argument("--lr", type=float, default=None, help="override G_lr / D_lr of the benchmark configuration (tuning aid)")
+    ap.add_argument("--conv-dtype", choices=("bf16", "fp8"), default=None, help="run the headline workload with this conv_dtype (tuning aid)")
     args = ap.parse_args()
 
     import _hip
@@ -348,6 +363,8 @@ def main():
         cfg = bench_config(which)
         if args.lr is not None:
             cfg.update(G_lr=args.lr, D_lr=args.lr)
+        if args.conv_dtype is not None and which == 1:
+            cfg.update(conv_dtype=args.conv_dtype)
         cfg["resolution"] = args.resolution
         cfg["hip_graph"] = not args.no_graph
         if args.resolution != 256:
@@ -369,7 +386,9 @@ def main():
            "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / steps,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
            "config": {"workload": desc3 if args.only_configs3 else desc1, "events_per_gpu_per_step": E,
-                      "parallelism": f"dp{world}", "clip_norm": cfg["clip_norm"], "hip_graph": bool(cfg["hip_graph"])},
+                      "parallelism": f"dp{world}", "clip_norm": cfg["clip_norm"], "hip_graph": bool(cfg["hip_graph"]),
+                      "lr": cfg["G_lr"], "regime": "D logits centred once (linear0.bias), lr small enough that both hinge terms stay active "
+                                                   "in every timed step (see hinge_unsaturated_in_every_timed_step)"},
            "losses_last_step": m["out"], "roofline": None, "cpu_baseline": None,
            "step_tflops_algorithmic": STEP_GFLOP * 1e-3 * world * steps / dt if (args.resolution == 256 and E == 1) else None,
            "git_head": git_head()}
