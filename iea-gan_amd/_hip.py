@@ -51,6 +51,12 @@ class Conv1x1BwdDesc(C.Structure):
                 ("out_mode", C.c_int), ("bn_acc", vp), ("dw", vp), ("partials", vp), ("colsum", vp), ("flags", C.c_int)]
 
 
+class DStemDesc(C.Structure):
+    _fields_ = [("img", vp), ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("w_in", vp), ("b_in", vp), ("w1", vp), ("b1", vp), ("wsc", vp),
+                ("bsc", vp), ("h1", vp), ("p0", vp), ("sc", vp), ("dh1", vp), ("dp0", vp), ("w1_bwd", vp), ("dw_in", vp), ("db_in", vp),
+                ("dw1", vp), ("db1", vp)]
+
+
 class ProfRec(C.Structure):
     _fields_ = [("name", C.c_char * 96), ("launches", C.c_long), ("ms", C.c_double),
                 ("flops", C.c_double), ("bytes", C.c_double), ("bytes_min", C.c_double)]
@@ -69,6 +75,8 @@ _SIGS = {
     "ieagan_conv1x1_bwd": [C.POINTER(Conv1x1BwdDesc), vp],
     "ieagan_conv1x1_bwd_workspace": [C.POINTER(Conv1x1BwdDesc)],
     "ieagan_conv1x1_bwd_supported": [i, i, i, i],
+    "ieagan_d_stem_fwd": [C.POINTER(DStemDesc), vp],
+    "ieagan_d_stem_bwd": [C.POINTER(DStemDesc), vp],
     "ieagan_effgrad": [vp, vp, vp, vp, vp, l, i, i, vp],
     "ieagan_prologue_bwd": [vp, vp, i, vp, vp, i, i, i, vp, vp, vp, i, i, i, i, vp, i, i, i, vp],
     "ieagan_bn_finalize_fwd": [vp, f, vp, vp, i, i, f, f, i, vp, vp, vp, vp, vp, i, i, i, vp],

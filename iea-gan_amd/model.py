@@ -308,6 +308,24 @@ class DBlock(nn.Module):
         if self.learnable_sc:
             self.conv_sc = which_conv(in_channels, out_channels - in_channels, kernel_size=1, padding=0)
 
+    def stem_ok(self, input_conv, x):
+        """Can ``ops.DStemFn`` take input_conv + this block's conv1 / conv_sc / pooled shortcut?  (the first block of the shipped
+        ch = 32 discriminator on a map whose height / width are multiples of 8 / 32)"""
+        return (ops.FUSE_D_STEM and x.is_cuda and x.dim() == 4 and x.shape[1] == 1 and x.shape[2] % 8 == 0 and x.shape[3] % 32 == 0
+                and input_conv.out_channels == 32 and self.in_channels == 32 and self.out_channels == 64 and self.hidden_channels == 16
+                and self.downsample is not None and not self.preactivation and self.learnable_sc
+                and all(c.bias is not None for c in (input_conv, self.conv1, self.conv_sc)))
+
+    def fused_stem(self, x, input_conv, recs, prefix):
+        """The block with its input side fused into one launch (ops.DStemFn): x is the fp32 image [N, 1, H, W]."""
+        link = ops.ResLink() if (torch.is_grad_enabled() and ops.FUSE_SHORTCUT_GRAD) else None    # conv4 -> stem backward
+        h, p0, sc = ops.DStemFn.apply(x, input_conv.weight, input_conv.bias, self.conv1.weight, self.conv1.bias, self.conv_sc.weight,
+                                      self.conv_sc.bias, recs["input_conv"], recs[prefix + ".conv1"], recs[prefix + ".conv_sc"], link)
+        h, _ = self.conv2.fused(h, recs[prefix + ".conv2"], relu=True)
+        h, _ = self.conv3.fused(h, recs[prefix + ".conv3"], relu=True)
+        out, _ = self.conv4.fused(h, recs[prefix + ".conv4"], relu=True, rs=2, ra=p0, Ca=self.in_channels, ra_rs=0, rb=sc, res_out=link)
+        return out
+
     def fused(self, xa, recs, prefix):
         rs = 2 if self.downsample else 0
         link = ops.ResLink() if (torch.is_grad_enabled() and ops.FUSE_SHORTCUT_GRAD) else None   # conv4 (-> conv_sc) -> conv1
@@ -411,9 +429,16 @@ class Discriminator(nn.Module):
     def forward(self, x, y=None):
         plan = self._prepare()
         recs = plan["bank"].run(self.training, self.SN_eps)
-        h = ops.InputConvFn.apply(x, self.input_conv.weight, self.input_conv.bias, recs["input_conv"])
+        first = self.blocks[0][0]
+        stem = isinstance(first, DBlock) and first.stem_ok(self.input_conv, x)
+        if stem:            # input_conv + the first block's three reads of its output: one launch (h0 never reaches HBM)
+            h = first.fused_stem(x, self.input_conv, recs, "blocks.0.0")
+        else:
+            h = ops.InputConvFn.apply(x, self.input_conv.weight, self.input_conv.bias, recs["input_conv"])
         for si, stage in enumerate(self.blocks):
             for bi, blk in enumerate(stage):
+                if stem and si == 0 and bi == 0:
+                    continue
                 p = f"blocks.{si}.{bi}"
                 h = blk.fused(h, recs, p)
         h = ops.ReluSumPoolFn.apply(h)                                             # global sum pool of relu -> [N, C] fp32

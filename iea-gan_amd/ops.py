@@ -966,6 +966,87 @@ class InputConvFn(torch.autograd.Function):
         return dimg, dW, dbias, None
 
 
+FUSE_D_STEM = True          # D.input_conv + the first DBlock's conv1 / conv_sc / pooled shortcut in one launch each way (csrc/d_stem.hip)
+
+
+class DStemFn(torch.autograd.Function):
+    """Input side of the first discriminator block: img -> (h1 = conv1(h0), p0 = AvgPool2d(h0), sc = conv_sc(p0)) with
+    h0 = input_conv(img) recomputed on chip (reference model.py:905 + 534-557).  ``link``: the ResLink the block's conv4 deposits its
+    out-gradient into (the pooled identity shortcut's share of d p0)."""
+
+    @staticmethod
+    def forward(ctx, img, w_in, b_in, w1, b1, wsc, bsc, rec_in, rec1, recsc, link):
+        N, _, Hh, Ww = img.shape
+        img = img.contiguous().float()
+        dev = img.device
+        h1 = torch.empty(N, Hh, Ww, 16, dtype=BF16, device=dev)
+        p0 = torch.empty(N, Hh // 2, Ww // 2, 32, dtype=BF16, device=dev)
+        sc = torch.empty(N, Hh // 2, Ww // 2, 32, dtype=BF16, device=dev)
+        d = H.DStemDesc(img.data_ptr(), N, Hh, Ww, rec_in.w_plain.data_ptr(), b_in.data_ptr(), rec1.w_fwd.data_ptr(), b1.data_ptr(),
+                        recsc.w_fwd.data_ptr(), bsc.data_ptr(), h1.data_ptr(), p0.data_ptr(), sc.data_ptr(), None, None, None, None, None, None, None)
+        H.call("ieagan_d_stem_fwd", d, H.stream())
+        ctx.recs, ctx.link = (rec_in, rec1, recsc), link
+        ctx.params = (w_in, b_in, w1, b1, wsc, bsc)
+        ctx.save_for_backward(img, p0)
+        return h1, p0, sc
+
+    @staticmethod
+    def backward(ctx, dh1, dp0, dsc):
+        img, p0 = ctx.saved_tensors
+        rec_in, rec1, recsc = ctx.recs
+        w_in, b_in, w1, b1, wsc, bsc = ctx.params
+        need = ctx.needs_input_grad
+        N, _, Hh, Ww = img.shape
+        Hp, Wp = Hh // 2, Ww // 2
+        dev = img.device
+        want_w = any(need[1:7])
+        dh1 = dh1.contiguous()
+        # ---- the identity-shortcut share of d p0: deposited by conv4 (channels [0, 32) of its out-gradient) or handed over by autograd
+        lg, lC, lCa = dp0, 32, 32
+        if ctx.link is not None and ctx.link.ready:
+            lg, lC, lCa, _ = ctx.link.take()
+        # ---- conv_sc backward: d p0 = dsc Wsc + shortcut share (+ its weight / bias gradients)
+        st = dsc.stride()
+        Cg = 32 if dsc.is_contiguous() else st[2]
+        dpt = torch.empty(N, Hp, Wp, 32, dtype=BF16, device=dev)
+        dWsc = dbsc = None
+        if want_w:
+            dwp = sn_scratch(recsc, "w", (32, recsc.kpad), dev)
+            colsum = sn_scratch(recsc, "b", (STAT_REPL, 32), dev)
+            d = H.Conv1x1BwdDesc(N, Hp, Wp, 32, 32, recsc.kpad, recsc.kpad2, H.src_desc(p0, 32, Hp, Wp, 0, None, None, 0, False), dsc.data_ptr(), Cg,
+                                 None, None, N, None, recsc.w_bwd.data_ptr(), H.ptr(lg), lC if lg is not None else 0, lCa if lg is not None else 0, 0,
+                                 dpt.data_ptr(), 1, None, dwp.data_ptr(), None, colsum.data_ptr(), FUSE_1X1_FLAGS)
+            ws_n = H.lib().ieagan_conv1x1_bwd_workspace(d)
+            if ws_n > 0:
+                ws = torch.empty(ws_n, dtype=torch.float32, device=dev)
+                d.partials = ws.data_ptr()
+            H.call("ieagan_conv1x1_bwd", d, H.stream())
+            dWsc, dbsc = sn_backward(dwp, wsc, recsc, colsum, bsc)
+        else:
+            _conv_launch(dsc, Cg, Hp, Wp, 0, None, None, 0, False, N, Hp, Wp, 32, 32, 1, recsc.kpad2, recsc.w_bwd, None, lg, lC if lg is not None else 0,
+                         lCa if lg is not None else 0, 0, None, 0, None, dpt, None)
+        dW_in = db_in = dW1 = db1 = dimg = None
+        if want_w:
+            dw_in = sn_scratch(rec_in, "w", (9, 32), dev)
+            cs_in = sn_scratch(rec_in, "b", (STAT_REPL, 32), dev)
+            dw1 = sn_scratch(rec1, "w", (16, rec1.kpad), dev)
+            cs1 = sn_scratch(rec1, "b", (STAT_REPL, 16), dev)
+            d = H.DStemDesc(img.data_ptr(), N, Hh, Ww, rec_in.w_plain.data_ptr(), b_in.data_ptr(), None, None, None, None, None, None, None,
+                            dh1.data_ptr(), dpt.data_ptr(), rec1.w_bwd.data_ptr(), dw_in.data_ptr(), cs_in.data_ptr(), dw1.data_ptr(), cs1.data_ptr())
+            H.call("ieagan_d_stem_bwd", d, H.stream())
+            dW_in, db_in = sn_backward(dw_in, w_in, rec_in, cs_in, b_in)
+            dW1, db1 = sn_backward(dw1, w1, rec1, cs1, b1)
+        if need[0]:
+            # the pass that trains G: d img = input_conv^T (dh1 W1 + 0.25 expand(d p0)) through the generic launches
+            dh0 = torch.empty(N, Hh, Ww, 32, dtype=BF16, device=dev)
+            _conv_launch(dh1, 16, Hh, Ww, 0, None, None, 0, False, N, Hh, Ww, 16, 32, 1, rec1.kpad2, rec1.w_bwd, None, dpt, 32, 32, 1, None, 0, None,
+                         dh0, None, ra_scale=0.25)
+            dimg = torch.empty(N, 1, Hh, Ww, dtype=torch.float32, device=dev)
+            H.call("ieagan_conv_Cto1", dh0.data_ptr(), None, None, 0, 0, rec_in.w_plain.data_ptr(), None, dimg.data_ptr(), 0, N, Hh, Ww, 32, 1,
+                   H.stream())
+        return dimg, dW_in, db_in, dW1, db1, dWsc, dbsc, None, None, None, None
+
+
 class OutputConvFn(torch.autograd.Function):
     """G.output_layer: BN apply + ReLU + 3x3 conv (C -> 1) + tanh -> fp32 [N,1,H,W]  (model.py:379-387, 487)."""
 

@@ -192,6 +192,37 @@ int ieagan_conv_Cto1(const void* x, const float* scale, const float* shift, int 
 int ieagan_wgrad_c1(const float* img, const float* tanh_y, const void* t, const float* scale, const float* shift,
                     int nstride, int relu, float* dw, int N, int H, int W, int C, int flip, void* stream);
 
+/* ---- input side of the first discriminator block in one launch each way (d_stem.hip) ---------------------------------------
+ * Replaces D.input_conv (3x3, 1 -> 32, model.py:905) + the three reads of its output by the first DBlock (conv1 1x1 32 -> 16, conv_sc on
+ * AvgPool2d, the pooled identity shortcut: model.py:534-557, first block: no pre-activation):
+ *   fwd:  img fp32 [N,H,W] -> h1 = conv1(h0) bf16 [N,H,W,16], p0 = AvgPool2d(h0) bf16 [N,H/2,W/2,32], sc = conv_sc(p0) bf16 [N,H/2,W/2,32],
+ *         h0 = input_conv(img) recomputed on chip, never stored;
+ *   bwd:  dh0 = dh1 W1 + 0.25 expand(dp0) (LDS only) -> dw_in [9][32] += , db_in [32][32 replicas] +=, dw1 [16][32] +=, db1 [32][16] +=
+ *         (weight gradients only: the pass that needs d img keeps the generic launches).
+ * w_in fp32 [9][32] (tap-major, / sigma), w1 / wsc the bf16 forward packs [Cout][32], w1_bwd the transposed pack [32][32].  H % 8 == 0, W % 32 == 0. */
+typedef struct {
+    const float* img;
+    int N, H, W;
+    const float* w_in;
+    const float* b_in;
+    const void* w1;
+    const float* b1;
+    const void* wsc;
+    const float* bsc;
+    void* h1;
+    void* p0;
+    void* sc;
+    const void* dh1;
+    const void* dp0;
+    const void* w1_bwd;
+    float* dw_in;
+    float* db_in;
+    float* dw1;
+    float* db1;
+} ieagan_d_stem_desc;
+int ieagan_d_stem_fwd(const ieagan_d_stem_desc* d, void* stream);
+int ieagan_d_stem_bwd(const ieagan_d_stem_desc* d, void* stream);
+
 /* ---- batched spectral norm (sn.hip): layers.SN.W_ / power_iteration (layers.py:89-165) -------- */
 int ieagan_sn_forward(const long* table, const int* blocks, int nblocks, const int* cblocks, int ncblocks,
                       float* params, float* ctx, float* part, void* pack, float eps, int training, void* stream);

@@ -501,3 +501,52 @@ def test_wgrad_side_stream_two_stage_and_fused_1x1_backward_do_not_change_the_st
     print(json.dumps({k: [round(rel_l2(pc[k], pb[k]), 5), round(rel_l2(pb[k], pa[k]), 5)] for k in pa if k.endswith("conv4.weight")}))
     for k in oa:
         assert abs(oa[k] - ob[k]) <= 2e-2 * max(1.0, abs(oa[k])), (k, oa[k], ob[k])
+
+
+@pytest.mark.parametrize("res,hb,n", [(64, 1, 6), (256, 3, 2)])
+def test_d_stem_kernel_matches_separate_launches(res, hb, n):
+    """ops.DStemFn (input_conv + the first DBlock's conv1 / conv_sc / pooled shortcut in one launch each way, h0 recomputed instead
+    of stored) against the separate launches on the same discriminator: logits / embeddings, EVERY parameter gradient of a D-phase
+    style backward (weights trained, image detached) and d img of a G-phase style backward (weights frozen)."""
+    import model, ops
+    from parity_util import O, build_product, make_cfg, rel_l2
+    cfg = make_cfg(resolution=res, H_base=hb, batch_size=n)
+    g_state, d_state = O.synth_nets(cfg, 101, 202)
+    x0 = O.synth_event(n, res, res * hb, 505).cuda()
+    y = torch.arange(n).cuda()
+    torch.manual_seed(5)
+    res_ = {}
+    for fused in (False, True):
+        ops.FUSE_D_STEM = fused
+        try:
+            _, D = build_product(cfg, g_state, d_state, "cuda:0")
+            _hip = __import__("_hip")
+            _hip.call("ieagan_prof_reset")
+            _hip.prof_enable(1)
+            pr, em, do = D(x0, y)
+            go = torch.linspace(-1, 1, n, device="cuda")
+            ge = torch.sin(torch.arange(em.numel(), device="cuda").float()).view_as(em) * 0.05
+            loss = (do * go).sum() + (em * ge).sum() + (pr * ge).sum()
+            grads = torch.autograd.grad(loss, [p for p in D.parameters()])
+            torch.cuda.synchronize()
+            _hip.prof_enable(0)
+            names = {r["name"] for r in _hip.prof_collect()}
+            assert ("d_stem_fwd" in names) == fused and ("d_stem_bwd" in names) == fused, names
+            _, D2 = build_product(cfg, g_state, d_state, "cuda:0")
+            for p in D2.parameters():
+                p.requires_grad_(False)
+            x1 = x0.clone().requires_grad_(True)
+            pr2, em2, do2 = D2(x1, y)
+            (gx,) = torch.autograd.grad((do2 * go).sum() + (em2 * ge).sum(), [x1])
+            res_[fused] = (do.detach(), em.detach(), {k: g for (k, _), g in zip(D.named_parameters(), grads)}, gx)
+        finally:
+            ops.FUSE_D_STEM = True
+    a, b = res_[False], res_[True]
+    assert rel_l2(b[0], a[0]) <= 5e-3 and rel_l2(b[1], a[1]) <= 5e-3, (rel_l2(b[0], a[0]), rel_l2(b[1], a[1]))
+    gmax = max(float(v.norm()) for v in a[2].values())
+    for k, ref in a[2].items():
+        if float(ref.norm()) < 1e-4 * gmax:
+            continue
+        err = rel_l2(b[2][k], ref)
+        assert err <= (3e-2 if k.startswith(("input_conv", "blocks.0.0")) else 2e-2), (k, err)
+    assert rel_l2(b[3], a[3]) <= 2e-2, rel_l2(b[3], a[3])
