@@ -557,8 +557,8 @@ def test_d_stem_kernel_matches_separate_launches(res, hb, n):
             _, D1 = build_product(cfg, g_state, d_state, "cuda:0")
             pr, em, do = D1(x0, torch.arange(n).cuda())
             go = torch.linspace(-1, 1, n, device="cuda")
-            grads = torch.autograd.grad((do * go).sum() + (em * torch.sin(torch.arange(em.numel(), device="cuda").float()).view_as(em)).sum(),
-                                        list(D1.parameters()))
+            ge = torch.sin(torch.arange(em.numel(), device="cuda").float()).view_as(em)
+            grads = torch.autograd.grad((do * go).sum() + (em * ge).sum() + (pr * ge).sum(), list(D1.parameters()))
             outs[fused] = (do.detach(), em.detach(), torch.cat([g.reshape(-1) for g in grads]))
         finally:
             ops.FUSE_D_STEM = True
