@@ -118,7 +118,7 @@ __device__ __forceinline__ void st_in_frags(const float* w_in, int lane, bf16x8 
         }
 }
 
-__global__ __launch_bounds__(256, 2) void d_stem_fwd_kernel(DStemArgs a, int tiles_w, int tiles_h) {
+__global__ __launch_bounds__(256, 3) void d_stem_fwd_kernel(DStemArgs a, int tiles_w, int tiles_h) {
     __shared__ float halo[ST_TH + 2][ST_TW + 4];
     __shared__ __attribute__((aligned(16))) float ot[4][16 * ST_LDO];
     __shared__ __attribute__((aligned(16))) bf16 h0t[4][64 * ST_XS];
@@ -385,7 +385,7 @@ extern "C" int ieagan_d_stem_fwd(const ieagan_d_stem_desc* d, void* stream) {
     ProfScope prof("d_stem_fwd", 2.0 * P * (9 * 32 + 32 * 16 + 0.25 * 32 * 32), P * (4.0 + 2.0 * (16 + 0.25 * 64)), st);
     const int tiles_w = d->W / ST_TW, tiles_h = d->H / ST_TH;
     const long ntl = (long)d->N * tiles_w * tiles_h;
-    const long blocks = ntl < 2048 ? ntl : 2048;
+    const long blocks = ntl < 768 ? ntl : 768;                    // one round of persistent blocks (41 KB of LDS: three per CU)
     hipLaunchKernelGGL(d_stem_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, stem_args(d), tiles_w, tiles_h);
     CHECK_LAUNCH("d_stem_fwd");
     return 0;
