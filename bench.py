@@ -273,12 +273,22 @@ def measure(cfg, args, rank, world, local, tag):
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    dp_slack = None
+    sync = parallel.get_context()
+    if sync is not None:
+        # data parallel: does the side stream's work (all-reduce + ortho + Adam + EMA) finish before the main stream asks for it?
+        # HIP-event pairs (side stream done, main stream arrives at its wait) over a few steps AFTER the timed region.
+        sync.trace = True
+        for _ in range(5):
+            step()
+        dp_slack = {k: [round(v, 3) for v in vs] for k, vs in sync.slack_ms().items()}
+        sync.trace = False
     parallel.set_context(None)
     if args.trace_losses and rank == 0:
         for i, o in enumerate(trace):
             print(f"[{tag}] step {i}: " + "  ".join(f"{k} {v:.4f}" for k, v in o.items()), file=sys.stderr)
     return dict(dt=dt, steps=steps, out=out, recs=recs, prof_steps=prof_steps, eager_timing=eager_timing, h=h, w=w, E=E,
-                timed_losses=trace[-steps:])
+                timed_losses=trace[-steps:], dp_slack=dp_slack)
 
 
 def kernel_report(res, m, args):
@@ -347,6 +357,8 @@ def main():
     ap.add_argument("--shape-tags", action="store_true", help="per-kernel timing split by layer shape (tuning aid)")
     ap.add_argument("--trace-losses", action="store_true", help="print the losses of every step to stderr (tuning aid)")
     ap.add_argument("--lr", type=float, default=None, help="override G_lr / D_lr of the benchmark configuration (tuning aid)")
+    ap.add_argument("--serial-wgrad", action="store_true", help="weight-gradient launches on the main stream (tuning aid: step time = sum of "
+                                                               "all launches + gaps; the difference to the kernel-time total is launch overhead)")
     ap.add_argument("--conv-dtype", choices=("bf16", "fp8"), default=None, help="run the headline workload with this conv_dtype (tuning aid)")
     args = ap.parse_args()
 
@@ -358,6 +370,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     _hip.require_gpu()
     torch.cuda.set_device(local)
+    if args.serial_wgrad:
+        import ops
+        ops.WGRAD_SIDE_STREAM = False
 
     def cfg_for(which):
         cfg = bench_config(which)
@@ -394,6 +409,9 @@ def main():
            "git_head": git_head()}
     sat = [o for o in m["timed_losses"] if not (o["D_loss_real"] > 0.0 and o["D_loss_fake"] > 0.0)]
     res["hinge_unsaturated_in_every_timed_step"] = not sat          # both D hinge terms > 0: every backward pass carries non-zero gradients
+    if m["dp_slack"] is not None:
+        res["dp_exchange_slack_ms"] = dict(m["dp_slack"], note="per step: ms between the side stream finishing a network's all-reduce + update and "
+                                           "the main stream reaching its wait for it (positive: fully hidden; negative: the main stream stalled)")
     if m["recs"]:
         kernel_report(res, m, args)
     if world == 1 and not args.no_configs3 and not args.only_configs3:
@@ -405,9 +423,9 @@ def main():
         res["configs3"] = r3
         m4 = measure(cfg_for(4), argparse.Namespace(**dict(vars(args), no_kernel_timing=True)), rank, world, local, "configs4")
         res["configs4"] = {"workload": "BASELINE configs[4] on ONE GPU: configs[1] with OCP e4m3 MFMA operands (per-slice weight scale, per-tile "
-                                       "activation scale, fp32 accumulate) in the forward C >= 64 3x3 convolutions; tensors in HBM stay bf16, "
-                                       "dgrad / wgrad bf16.  Non-scaled fp8 MFMA runs at the bf16 rate on gfx950: a precision / footprint "
-                                       "variant, not a faster one", "value": m4["E"] * m4["steps"] / m4["dt"], "unit": "events/s",
+                                       "activation scale, fp32 accumulate; block-scaled K = 128 instruction v_mfma_scale_f32_16x16x128_f8f6f4 with "
+                                       "unit block scales) in the forward AND dgrad launches of the C = 128 3x3 convolutions and of the C = 64 ones "
+                                       "with >= 1000 tile-blocks; tensors in HBM stay bf16, wgrad bf16", "value": m4["E"] * m4["steps"] / m4["dt"], "unit": "events/s",
                            "steps": m4["steps"], "ms_per_step": 1e3 * m4["dt"] / m4["steps"], "dtype": "fp8 (e4m3) operands / bf16 tensors",
                            "losses_last_step": m4["out"], "tolerance": "tests/test_networks_gpu.py::test_fp8_conv_path_forward_and_step_tolerance"}
     if world == 1 and not args.no_cpu_baseline:

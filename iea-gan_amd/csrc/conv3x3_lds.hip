@@ -612,7 +612,7 @@ static int lds_fp8_launch(const ConvArgs& a, hipStream_t st) {
                                st, a, tiles_w, tiles_h, tpe, tpb, nblk, bpe);                                                      \
         return 1;                                                                                                                  \
     }
-    // (C = 64 on the small maps -- fewer than 400 tile-blocks -- stays with the bf16 4-wave 8x16 form: more, smaller blocks; measured)
+    // (C = 64 on the small maps -- fewer than 1000 tile-blocks -- stays with the bf16 4-wave 8x16 form: more, smaller blocks; measured)
     if (a.Cin == 64 && a.Cout % 64 == 0 && a.H >= 8 && a.W >= 32 &&
         (long)a.N * ((a.H + 7) / 8) * ((a.W + 31) / 32) * (a.Cout / 64) >= 1000) F8_LAUNCH(64, 4, 8, 32, 4)
     if (a.Cin == 128 && a.Cout % 32 == 0 && a.H >= 8 && a.W >= 16) F8_LAUNCH(128, 2, 8, 16, 4)

@@ -498,7 +498,13 @@ class G_D(nn.Module):
         self.G, self.D = G, D
 
     def forward(self, z, gy, x=None, dy=None, x_aug=None, contra=True, train_G=False, return_G_z=False, split_D=False,
-                diff_aug=True, pixel_reg=False):
+                diff_aug=True, pixel_reg=False, real_first=False, real_out=None):
+        """``real_first`` (split_D, D phase): evaluate D(x) BEFORE G(z) -> D(G(z)) -- data-parallel runs hide G's gradient exchange +
+        update behind the real pass this way (the reference order is fake, then real: model.py:987, 1002; swapping it changes which
+        spectral-norm iterate each pass sees, a tolerance-level deviation).  ``real_out``: D(x, dy) already evaluated
+        by the caller (segmented graph replay)."""
+        if real_first and real_out is None and split_D and x is not None and not train_G:
+            real_out = self.D(x, dy)
         with torch.set_grad_enabled(train_G):
             G_z = self.G(z, gy)
             if diff_aug:
@@ -511,9 +517,9 @@ class G_D(nn.Module):
             if contra:
                 if train_G:
                     return (*fake, G_z, G_reg) if return_G_z else fake
-                return (*fake, *self.D(x, dy))
+                return (*fake, *(real_out if real_out is not None else self.D(x, dy)))
             if x is not None:
-                return fake, self.D(x, dy)
+                return fake, (real_out if real_out is not None else self.D(x, dy))
             return (fake, G_z, G_reg) if return_G_z else fake
         # joint pass over the concatenated batch
         parts, labels = [G_z], [gy]

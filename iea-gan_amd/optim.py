@@ -38,6 +38,11 @@ class FusedAdam(torch.optim.Optimizer):
             return super().zero_grad(set_to_none=set_to_none)
         self._arena().attach_grads()
 
+    def hyper_dirty(self):
+        """True when ``push_hyper`` would write the device block (first call, or lr / betas / eps changed on the host)."""
+        g = self.param_groups[0]
+        return self._hp is None or (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"])) != self._hp_host
+
     def push_hyper(self):
         """Mirror lr / betas / eps into the device block the kernel reads (no-op when unchanged); called
         by ``step`` and, when the train step is replayed from a HIP graph, once per replay."""

@@ -29,6 +29,8 @@ class GradSync:
         self.force = force and dist.is_initialized()      # exercise the collective path with a 1-rank group (tests)
         self._stream = None
         self._pending = {}
+        self.trace = False          # record (side work done, main stream arrives at the wait) event pairs: slack_ms()
+        self._slack = []
 
     def _side_stream(self):
         if self._stream is None:
@@ -52,9 +54,9 @@ class GradSync:
                 flat_grad.mul_(1.0 / self.world)
                 if then is not None:
                     then()
-                done = torch.cuda.Event()
+                done = torch.cuda.Event(enable_timing=self.trace)
                 done.record(side)
-            self._pending[key] = done
+            self._pending[key] = (done, self.trace)
         else:
             dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
             flat_grad.mul_(1.0 / self.world)
@@ -62,9 +64,23 @@ class GradSync:
                 then()
 
     def wait(self, key):
-        ev = self._pending.pop(key, None)
+        ev, timed = self._pending.pop(key, (None, False))
         if ev is not None:
+            if timed and not torch.cuda.is_current_stream_capturing():
+                arrive = torch.cuda.Event(enable_timing=True)
+                arrive.record()                     # the moment the consumer stream asks for the result
+                self._slack.append((key, ev, arrive))
             torch.cuda.current_stream().wait_event(ev)
+
+    def slack_ms(self):
+        """Per key, for every traced exchange: milliseconds between the side stream finishing (all-reduce + update) and the consumer
+        stream reaching its wait.  Positive = the exchange was hidden completely; negative = the consumer stalled that long."""
+        torch.cuda.synchronize()
+        out = {}
+        for key, done, arrive in self._slack:
+            out.setdefault(key, []).append(done.elapsed_time(arrive))
+        self._slack = []
+        return out
 
     def wait_all(self):
         for k in list(self._pending):

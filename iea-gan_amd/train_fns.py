@@ -167,6 +167,11 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
     # Data parallel: the step is three graphs with eager all-reduces between them, and a pass issued in one graph cannot be handed to
     # the next -- only the passes that are issued AND consumed inside the D phase go ahead (3 of the step's 5).
     sn_local = sn_known and sync is not None
+    # Data parallel: D(x_real) is evaluated BEFORE G(z) in the D phase (GD(real_first=True)), and only then does the main stream wait
+    # for G's side-stream all-reduce + ortho + Adam + EMA of the previous step -- they run under the real pass instead of in front of
+    # the step.  Deviation from the reference's fake-then-real order: the two passes see swapped spectral-norm iterates
+    # (tolerance level, 9-Q6); single-GPU runs keep the reference order.
+    real_first = sync is not None and bool(config.get("dp_real_first", True)) and config["split_D"] and config["num_D_accumulations"] == 1
 
     def prefetch_sn(net, passes, local=False):
         if not (sn_ahead or (local and sn_local)) or not next(net.parameters()).is_cuda:
@@ -189,16 +194,37 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
         if z_.shape[0] < chunk:
             raise ValueError(f"z_ holds {z_.shape[0]} latent rows, one pass needs {chunk} (prepare_z_y(batch_size * events_per_step, ...))")
 
+    def d_real_forward():
+        """Data parallel, real_first: D(x_real) alone -- nothing here touches G (whose update may still be running on the side
+        stream).  Returns a dummy tensor; the outputs (with their autograd tape) wait in ``st['real_out']``."""
+        x, y = st["x"], st["y"]
+        prefetch_sn(D, 1, local=True)
+        D.optim.zero_grad()
+        if config["toggle_grads"]:
+            utils.toggle_grad(D, True)
+        st["real_out"] = D(torch.split(x, chunk)[0], torch.split(y, chunk)[0])
+        return torch.zeros((), device=x.device)
+
     def d_forward_backward():
         """Zero both gradient arenas, accumulate D's gradient (train_fns.py:24-130); returns [real, fake, unif_d]."""
         x, y = st["x"], st["y"]
+        real_out = st.pop("real_out", None) if real_first else None
+        if real_first and real_out is None:     # not segmented: the real pass first, in here
+            d_real_forward()
+            real_out = st.pop("real_out")
+        if real_first:
+            sync.wait("G")                      # G's exchange + update (side stream) ran under the real pass: join before G is touched
         if sn_local:
             prefetch_sn(G, 1, local=True)       # this phase's generator pass
         else:
             prefetch_sn(G, 2)                   # both generator passes of the step: G's weights only change in g_update
-        prefetch_sn(D, 3 if config["Con_reg"] else 2, local=True)      # D(fake), D(real)[, D(real_aug)]: D's weights change in d_update
+        if real_first:
+            prefetch_sn(D, 2 if config["Con_reg"] else 1, local=True)      # D(fake)[, D(real_aug)]
+        else:
+            prefetch_sn(D, 3 if config["Con_reg"] else 2, local=True)      # D(fake), D(real)[, D(real_aug)]: D's weights change in d_update
         G.optim.zero_grad()
-        D.optim.zero_grad()
+        if not real_first:
+            D.optim.zero_grad()
         x_aug = None
         if config["Con_reg"]:
             x_aug = CR_DiffAug(x, draws=explicit("cr") if st["noise"] is not None else None)
@@ -214,7 +240,7 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
             sample("d")
             joint_aug = config["Con_reg"] and not config["split_D"]
             outs = GD(z_[:chunk], ys[c], xs[c], ys[c], xa[c] if joint_aug else None, contra=contra, train_G=False,
-                      split_D=config["split_D"], diff_aug=config["diff_aug"])
+                      split_D=config["split_D"], diff_aug=config["diff_aug"], real_out=real_out)
             aug_out = None
             if contra:
                 if len(outs) == 8:
@@ -321,7 +347,7 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
         elif then is not None:
             then()
 
-    def step_tensor(run_d, run_g, run_gu, replayed=False):
+    def step_tensor(run_d, run_g, run_gu, replayed=False, run_dr=None):
         """[G_loss, D_loss_real, D_loss_fake, unif_loss_d, iea_loss] as one device tensor (no host sync)."""
         for _ in range(config["num_D_steps"]):
             if sync is not None:
@@ -329,7 +355,11 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
                 # first thing: order the main stream behind them here (eager: the forward pre-hook fires too late for
                 # zero_grad(); replayed: a graph runs no Python hooks at all)
                 sync.wait("D")
-                sync.wait("G")          # likewise G's update of the previous step (it zeroes / reads G's gradient arena)
+                if not real_first:
+                    sync.wait("G")      # likewise G's update of the previous step (it zeroes / reads G's gradient arena)
+                elif run_dr is not None:
+                    run_dr()            # segmented replay: D(x_real) as its own graph, G's update still in flight beside it
+                    sync.wait("G")
             dv = run_d()
             reduce(D, "D", d_update)
             if not replayed:
@@ -342,7 +372,7 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
 
     def whole_step():
         try:
-            return step_tensor(d_forward_backward, g_forward_backward, g_update)
+            return step_tensor(d_forward_backward, g_forward_backward, g_update)     # (real_first: d_forward_backward runs the real pass itself)
         except BaseException:
             # a step that ends early must not leave spectral-norm passes queued: the next forward would silently consume a pass
             # computed from older weights / an older u (every later step shifted by one pass)
@@ -355,6 +385,7 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
     use_graph = bool(config.get("hip_graph", False))
     whole = _Replay(whole_step)
     seg = (_Replay(d_forward_backward), _Replay(g_forward_backward), _Replay(g_update))
+    seg_real = _Replay(d_real_forward) if real_first else None        # data parallel + graphs: D(x_real) is a graph of its own
 
     def push_device_state():
         for net in (G, D):
@@ -372,18 +403,20 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
             return dict(zip(KEYS, vals.tolist()))
         if st.get("static") is None or st["x"].shape != x.shape or st["y"].shape != y.shape:
             st["x"], st["y"], st["static"] = x.clone(), y.clone(), True     # static inputs of the captured graphs
-            for r in (whole, *seg):     # graphs captured against the previous static buffers / shapes are stale
+            for r in (whole, *seg, *([seg_real] if seg_real is not None else [])):     # graphs captured against the previous static buffers / shapes are stale
                 r.reset()
         st["x"].copy_(x)
         st["y"].copy_(y)
         st["noise"] = None
-        if sync is not None:
+        if sync is not None and (G.optim.hyper_dirty() or D.optim.hyper_dirty() or (config["ema"] and ema.decay_dirty(state_dict["itr"]))):
             # the previous step's side-stream Adam / EMA still READ the lr / decay block that the push below rewrites on the
-            # main stream: join them first, or which step sees a new value is timing-dependent per rank (replicas diverge)
+            # main stream: join them first, or which step sees a new value is timing-dependent per rank (replicas diverge).
+            # Only when there IS something to push (a scheduler step, the EMA start iteration): an unconditional join here would
+            # put G's exchange back in front of the step.
             sync.wait("D")
             sync.wait("G")
         push_device_state()                               # lr / decay changes reach the graphs through device memory
-        vals = whole() if sync is None else step_tensor(*seg, replayed=True)
+        vals = whole() if sync is None else step_tensor(*seg, replayed=True, run_dr=seg_real)
         return dict(zip(KEYS, vals.tolist()))
 
     def step_eager_tensor(x, y):

@@ -128,6 +128,11 @@ class apply_ema(object):
             out.append(a)
         return out
 
+    def decay_dirty(self, itr=None):
+        """True when ``push_decay(itr)`` would write the device scalar."""
+        decay = 0.0 if (itr and itr < self.start_itr) else self.decay
+        return self._decay_dev is None or decay != self._decay_host
+
     def push_decay(self, itr=None):
         """Mirror the decay for iteration ``itr`` into the device scalar the kernel reads (no-op when
         unchanged); called by ``update`` and once per replay when the step runs from a HIP graph."""

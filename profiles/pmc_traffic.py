@@ -13,7 +13,10 @@ from collections import defaultdict
 def family(name):
     n = re.sub(r"^void ", "", name)
     if n.startswith("conv_gather_kernel<1") or n.startswith("conv1x1_stream_kernel"): return "conv1x1_gather"      # (bench.py family names)
-    if n.startswith("conv3x3_lds_kernel") or n.startswith("conv3x3_ws_kernel"): return "conv3x3_halo"
+    if n.startswith("conv3x3_lds_kernel") or n.startswith("conv3x3_lds_fp8_kernel") or n.startswith("conv3x3_ws_kernel"): return "conv3x3_halo"
+    if n.startswith("conv1x1_bwd_kernel"): return "conv1x1_bwd"
+    if n.startswith("d_stem_fwd_kernel"): return "d_stem_fwd"
+    if n.startswith("d_stem_bwd_kernel"): return "d_stem_bwd"
     if n.startswith("wgrad_reduce_kernel"): return "conv3x3_wgrad"
     if n.startswith("conv_gather_kernel<9"): return "conv3x3_gather"
     if n.startswith("conv3x3_halo_kernel"): return "conv3x3_halo"
@@ -25,7 +28,8 @@ def family(name):
                      ("ema_kernel", "ema_update"), ("bn_finalize_fwd", "bn_finalize_fwd"), ("bn_finalize_bwd", "bn_finalize_bwd"),
                      ("res_bwd", "res_bwd"), ("diffaug", "diffaug"), ("maxpool2", "maxpool2"), ("gamma_residual", "gamma_residual"),
                      ("rrm_attn", "rrm_attention"), ("loss_block", "loss_block"), ("relu_sum_pool", "relu_sum_pool"),
-                     ("nchw_to_nhwc", "nchw_to_nhwc"), ("nhwc_to_nchw", "nhwc_to_nchw")):
+                     ("nchw_to_nhwc", "nchw_to_nhwc"), ("nhwc_to_nchw", "nhwc_to_nchw"), ("slin_fwd", "slin_fwd"), ("slin_bwd", "slin_bwd"),
+                     ("ln_fwd", "ln_fwd"), ("ln_bwd", "ln_bwd"), ("embed_norm", "embed_norm")):
         if key in n:
             return fam
     return "library (ATen/rocBLAS/RCCL)"

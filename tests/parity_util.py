@@ -99,7 +99,7 @@ def _flat_grads(net, grads):
 
 
 def step_parity(resolution=64, H_base=1, device="cuda:0", verbose=False, n=40, events=1, state_check=False, oracle_bf16=False,
-                inputs=None, y_g=None, **cfg_over):
+                inputs=None, y_g=None, sn_warm=0, **cfg_over):
     """One full train(x, y) on the HIP path vs the oracle on identical weights / noise: the 5 losses and the flat G / D
     gradients (cosine, rel-L2); with ``state_check`` also the post-step state (parameters after Adam, spectral-norm
     ``u0`` / ``sv0``, BatchNorm running statistics).  ``n`` < 40 runs a sub-event of the first n sensors (full
@@ -114,6 +114,16 @@ def step_parity(resolution=64, H_base=1, device="cuda:0", verbose=False, n=40, e
     cfg = make_cfg(resolution=resolution, H_base=H_base, batch_size=n, events_per_step=events, **over)
     hh, ww = resolution, resolution * H_base
     g_state, d_state = O.synth_nets(cfg, 101, 202)
+    if sn_warm:
+        # converge the spectral-norm power iteration first (``sn_warm`` training-mode oracle passes advance u0 / sv0 in place): a fresh
+        # u0 is random, its first iterates move sigma by O(1) -- a run that is only allowed to differ in WHICH iterate a pass sees
+        # (data-parallel real-first order) has to be compared where consecutive iterates agree, as they do after a few steps
+        gw = torch.Generator().manual_seed(17)
+        with torch.no_grad():
+            for _ in range(sn_warm):
+                zz, rr = torch.randn(n, 128, generator=gw), torch.randn(n, 4, generator=gw)
+                gz = O.generator(g_state, cfg, zz, torch.arange(n), rr, True)
+                O.discriminator(d_state, cfg, gz, torch.arange(n), True)
     G, D = build_product(cfg, g_state, d_state, device)
     GD = model.G_D(G, D)
     z_, y_ = utils.prepare_z_y(n * events, G.dim_z, cfg["n_classes"], device=device)

@@ -267,8 +267,8 @@ def test_streaming_1x1_agrees_with_gather(dev, Cin, Cout, Hh, Ww, N, aff, relu, 
         assert not torch.allclose(outs[0][1][0], outs[0][1][1])          # the events really are separate accumulators
 
 
-@pytest.mark.parametrize("N,Hh,Ww,C,aff", [(8, 64, 192, 64, False), (6, 32, 96, 64, True), (5, 20, 40, 64, False), (4, 16, 48, 128, True),
-                                            (3, 8, 24, 128, False)])
+@pytest.mark.parametrize("N,Hh,Ww,C,aff", [(24, 64, 192, 64, False), (84, 32, 96, 64, True), (170, 20, 40, 64, False), (8, 64, 192, 64, False),
+                                            (4, 16, 48, 128, True), (3, 8, 24, 128, False)])
 def test_fp8_forward_conv_vs_bf16_and_fp32(dev, N, Hh, Ww, C, aff):
     """BASELINE configs[4]: the C = 64 / 128 3x3 forward launches with OCP e4m3 MFMA operands (per-slice weight scale, per-tile
     activation scale, fp32 accumulate).  Stated tolerance: relative L2 error of the output <= 4e-2 against fp32 (e4m3 carries 3
@@ -298,6 +298,11 @@ def test_fp8_forward_conv_vs_bf16_and_fp32(dev, N, Hh, Ww, C, aff):
     e16, e8 = rel(outs["bf16"][0]), rel(outs["fp8"][0])
     print(f"rel-L2 vs fp32: bf16 {e16:.2e}, fp8 {e8:.2e}")
     assert e16 <= 6e-3 and e8 <= 4e-2, (e16, e8)
+    if C == 64 and N * ((Hh + 7) // 8) * ((Ww + 31) // 32) < 1000:
+        # C = 64 below 1000 tile-blocks keeps bf16 operands whatever the flag says (conv3x3_lds.hip, lds_fp8_launch: the 8-wave fp8
+        # form is slower than the 4-wave bf16 form there): the flag must then change NOTHING
+        assert torch.equal(outs["fp8"][0], outs["bf16"][0])
+        return
     assert e8 > e16                                        # the fp8 path really ran with fp8 operands
     # the block-scaled K = 128 instruction (all block scales 1) sums the SAME e4m3 products as four K = 32 instructions: only the
     # fp32 accumulation order differs (a wrong k pairing of the two operands would be an O(1) error)
@@ -880,7 +885,8 @@ def test_fused_1x1_backward_matches_separate_launches(dev, ref_cfg, kind, cin, c
         assert err <= 1e-2, (k, err)
 
 
-@pytest.mark.parametrize("N,Hh,Ww,C,aff", [(8, 64, 192, 64, True), (6, 32, 96, 64, False), (4, 16, 48, 128, True), (3, 8, 24, 128, False)])
+@pytest.mark.parametrize("N,Hh,Ww,C,aff", [(24, 64, 192, 64, True), (84, 32, 96, 64, False), (6, 32, 96, 64, False), (4, 16, 48, 128, True),
+                                            (3, 8, 24, 128, False)])
 def test_fp8_conv_dgrad_vs_fp32(dev, N, Hh, Ww, C, aff):
     """conv_dtype='fp8' dgrad of the C = 64 / 128 3x3 layers (plain prologue; ReLU-mask epilogue for the D layers, BatchNorm-backward
     epilogue for the G layers) through ops.conv's autograd: gradient w.r.t. the conv input against fp32 autograd of the same
@@ -909,4 +915,8 @@ def test_fp8_conv_dgrad_vs_fp32(dev, N, Hh, Ww, C, aff):
         (gx,) = torch.autograd.grad((out.float() * nhwc(go).float()).sum(), [xa])
         errs[name] = float((nchw(gx) - gx_ref).norm() / gx_ref.norm())
     print(errs)
-    assert errs["bf16"] <= 1.5e-2 and errs["fp8"] <= 5e-2 and errs["fp8"] > errs["bf16"], errs
+    assert errs["bf16"] <= 1.5e-2 and errs["fp8"] <= 5e-2, errs
+    if C == 64 and N * ((Hh + 7) // 8) * ((Ww + 31) // 32) < 1000:
+        assert errs["fp8"] == errs["bf16"], errs        # below 1000 tile-blocks C = 64 keeps bf16 operands (lds_fp8_launch): the flag is inert
+    else:
+        assert errs["fp8"] > errs["bf16"], errs

@@ -448,6 +448,27 @@ def test_data_parallel_path_single_rank_rehearsal(graph):
     assert rec["n_gpus"] == 1 and rec["value"] > 0 and all(np.isfinite(v) for v in rec["losses_last_step"].values()), rec
 
 
+@pytest.mark.parametrize("real_first", [True, False])
+def test_data_parallel_step_vs_oracle_single_rank(real_first):
+    """One train(x, y) through the data-parallel path (1-rank RCCL group: side-stream all-reduce + ortho + Adam, main-stream waits)
+    against the oracle: losses, flat gradients and the post-step state.  ``real_first`` (the data-parallel default) evaluates
+    D(x_real) BEFORE G(z) -> D(fake) so that G's exchange + update of the previous step run under it; the oracle keeps the reference's
+    fake-then-real order (train_fns.py:45-51 via model.py:987-1002), so this also bounds what the swap costs: the two passes see
+    exchanged spectral-norm iterates, nothing else."""
+    import subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29537" if real_first else "29539")
+    r = subprocess.run([sys.executable, os.path.join(here, "dp_rehearsal.py"), "1" if real_first else "0"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    rep = json.loads(r.stdout.strip().splitlines()[-1])
+    print(json.dumps(rep))
+    assert rep["ok"], rep
+    st = rep["state"]
+    assert st["D_u0_rel_max"] < 2e-2 and st["G_u0_rel_max"] < 2e-2, st
+    assert st["D_update_sign_agree"] > 0.9 and st["G_update_sign_agree"] > 0.9, st
+
+
 def test_wgrad_side_stream_two_stage_and_fused_1x1_backward_do_not_change_the_step():
     """Weight-gradient launches on the side stream / two-stage accumulation / the fused 1x1 backward (the defaults) against the plain
     form -- every launch on one stream, float atomics, separate effgrad / dgrad / wgrad launches -- on the same nets, event and
