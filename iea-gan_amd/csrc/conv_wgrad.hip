@@ -317,35 +317,48 @@ static void launch_wgrad_pro(const WgradArgs& a, hipStream_t st, int mt, dim3 gr
     else launch_wgrad_mt<TAPS, false, false, RS, TR>(a, st, mt, grid, lds, special);
 }
 
-// Second stage of the two-stage accumulation: dw[row][k] += sum over the S pixel-split slabs, k < K.  grid (K/4 float4 columns in
-// blocks of 256, rows, slab chunks of RED_CHUNK): consecutive threads read consecutive float4 of one slab row.
-#define RED_CHUNK 32
+// Second stage of the two-stage accumulation: dw[row][k] += sum over the S pixel-split slabs, k < K.  A block is 64 float4 columns
+// of the FLAT [Cout][Kpad] slab x 4 slab lanes (the first form mapped a 256-thread block onto the K/4 float4 columns of ONE row:
+// 4..36 live threads per block for the 1x1 / C = 16 layers, each walking 32 slabs serially); the four lanes meet in LDS, slab
+// chunks (blockIdx.y, at most 32 so that no address sees more than 32 atomics) in float atomics.
 #define WG_TWO_STAGE_MIN_BYTES (8L << 20)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, int chunk, int Cout, int Kpad, int K) {
-    const int c4 = blockIdx.x * 256 + threadIdx.x;
-    const int row = blockIdx.y;
-    if (c4 * 4 >= K) return;
-    const int s0 = blockIdx.z * chunk, s1 = min(s0 + chunk, S);
-    const long slab = (long)Cout * Kpad;
-    const float* p = part + (long)row * Kpad + c4 * 4;
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, int chunk, int n4, int kp4, int K) {
+    __shared__ f32x4 red[3][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + tx;
+    const bool live = i < n4 && (i % kp4) * 4 < K;            // Kpad padding columns are not written by the first stage
+    const int s0 = blockIdx.y * chunk, s1 = min(s0 + chunk, S);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-    for (int s = s0; s < s1; ++s) acc += *(const f32x4*)(p + (long)s * slab);
-    float* d = dw + (long)row * Kpad + c4 * 4;
-    if (gridDim.z == 1) {
+    if (live) {
+        const f32x4* p = (const f32x4*)part + i;
+#pragma unroll 4
+        for (int s = s0 + ty; s < s1; s += 4) acc += p[(long)s * n4];
+    }
+    if (ty > 0) red[ty - 1][tx] = acc;
+    __syncthreads();
+    if (ty > 0 || !live) return;
+    acc += red[0][tx] + red[1][tx] + red[2][tx];
+    float* d = dw + (long)i * 4;
+    if (gridDim.y == 1) {
         f32x4 v = *(f32x4*)d;
         *(f32x4*)d = v + acc;
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) atomicAdd(d + i, acc[i]);
+        for (int j = 0; j < 4; ++j) atomicAdd(d + j, acc[j]);
     }
 }
 
-// second stage for other producers of partial slabs (conv1x1_bwd.hip)
+// second stage, also for other producers of partial slabs (conv1x1_bwd.hip)
 int wgrad_reduce_launch(const float* part, float* dw, int S, int Cout, int Kpad, int K, hipStream_t st) {
-    const int zc = S > 2 * RED_CHUNK ? (S + RED_CHUNK - 1) / RED_CHUNK : 1;
+    const int n4 = Cout * (Kpad / 4);
+    const int bx = (n4 + 63) / 64;
+    int zc = (512 + bx - 1) / bx;                   // ~2 blocks per CU
+    if (zc > 32) zc = 32;
+    if (zc > (S + 15) / 16) zc = (S + 15) / 16;     // at least 16 slabs per block (4 per lane)
+    if (zc < 1) zc = 1;
     const int chunk = (S + zc - 1) / zc;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((K / 4 + 255) / 256, Cout, zc), dim3(256), 0, st, part, dw, S, chunk, Cout, Kpad, K);
+    zc = (S + chunk - 1) / chunk;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(bx, zc), dim3(256), 0, st, part, dw, S, chunk, n4, Kpad / 4, K);
     CHECK_LAUNCH("wgrad_reduce");
     return 0;
 }
@@ -446,11 +459,8 @@ int conv_wgrad_launch(const WgradArgs& a0, hipStream_t st, int use_tr) {
 #undef WG_DISPATCH
     CHECK_LAUNCH("conv_wgrad");
     if (a.partials != nullptr) {          // second stage: fold the gx slabs into dw
-        const int K = a.taps * a.Cin;
-        const int zc = p.gx > 2 * RED_CHUNK ? (p.gx + RED_CHUNK - 1) / RED_CHUNK : 1;       // few slabs: one pass, no atomics
-        const int chunk = (p.gx + zc - 1) / zc;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((K / 4 + 255) / 256, a.Cout, zc), dim3(256), 0, st, a.partials, a.dw, p.gx, chunk, a.Cout, a.Kpad, K);
-        CHECK_LAUNCH("wgrad_reduce");
+        const int rc = wgrad_reduce_launch(a.partials, a.dw, p.gx, a.Cout, a.Kpad, a.taps * a.Cin, st);
+        if (rc != 0) return rc;
     }
     return 0;
 }
