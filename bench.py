@@ -43,6 +43,7 @@ PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH
 PEAK_HBM_GBS = 8000.0         # HBM3E spec (6.3 TB/s measured achievable)
 STEP_GFLOP = 5328.8           # algorithmic work per event-step (SURVEY 8d / BASELINE.md section 3)
 BENCH_LR = 1e-7               # see bench_config(): keeps both hinge terms of D unsaturated over the timed steps
+CPU_FULL_FILES = ("r03_cpu_full.json", "r02_cpu_full.json")                                      # newest first
 PMC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_final_pmc_traffic.json")      # newest first
 
 
@@ -128,8 +129,21 @@ def cpu_baseline(cfg, mode="sub", threads=None):
               f"(warm-up {times[0]:.1f} s)" if mode == "full" else
               f"one oracle train step (fp32, PyTorch CPU) at 256x768 on {sensors} of 40 sensors: {dt:.1f} s, "
               f"scaled x{40 // sensors} to a full event")
-    return {"value": 1.0 / (dt * 40.0 / sensors), "unit": "events/s", "cores": threads, "kind": "port", "sample": sample,
-            "host_logical_cpus_available": avail, "host_physical_cores": physical_cores()}
+    res = {"value": 1.0 / (dt * 40.0 / sensors), "unit": "events/s", "cores": threads, "kind": "port", "sample": sample,
+           "host_logical_cpus_available": avail, "host_physical_cores": physical_cores()}
+    if mode != "full":
+        # next to the bounded sample: the full 40-sensor step as last recorded with --cpu-baseline full (committed, not re-timed here)
+        for name in CPU_FULL_FILES:
+            path = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(path):
+                try:
+                    full = json.load(open(path)).get("cpu_baseline") or {}
+                    res["full_event_recorded"] = {"value": full.get("value"), "unit": full.get("unit"), "cores": full.get("cores"),
+                                                  "sample": full.get("sample"), "source": f"profiles/{name}"}
+                except Exception as e:
+                    print(f"bench: cannot read {path}: {e}", file=sys.stderr)
+                break
+    return res
 
 
 def pmc_families():
