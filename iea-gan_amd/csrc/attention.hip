@@ -38,6 +38,29 @@ __device__ __forceinline__ bf16x8 trfrag(const bf16* tile, int stride, int c0, i
     return f;
 }
 
+// Swizzled LDS tiles (backward kernels): the 16-byte chunk c of row r of a [32][W] tile lives at chunk position c ^ key(r), with
+// key(r) = r & 15 for W = 128 (16 chunks per row) and (r >> 2) & 3 for W = 32 (4 chunks per row).  A-fragment reads (lane lr reads
+// row lr, one chunk: rows 256 / 64 bytes apart would all hit the same banks) and the transposed B-fragment reads then spread over
+// all banks; staging writes apply the same key.
+template <int W>
+__device__ __forceinline__ int swz_key(int r) { return W == 128 ? (r & 15) : W == 64 ? (r & 7) : ((r >> 2) & 3); }
+template <int W>
+__device__ __forceinline__ int swz_off(int r, int c) { return r * W + ((c ^ swz_key<W>(r)) << 3); }      // bf16 elements
+// B fragment (as trfrag) from a swizzled tile
+template <int W>
+__device__ __forceinline__ bf16x8 trfrag_swz(const bf16* tile, int c0, int lr, int lg) {
+    const int q = lr >> 2, p = lr & 3;
+    const int row = 4 * lg + q;                                   // rows row and row + 16 share the key
+    const bf16* p0 = tile + swz_off<W>(row, (c0 >> 3) + (p >> 1)) + 4 * (p & 1);
+    const bf16* p1 = p0 + 16 * W;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)p0);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)p1);
+    bf16x8 f;
+    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+    f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+    return f;
+}
+
 // 8 consecutive features [8g, 8g+8) of row `row` of a [rows][width] bf16 matrix (zero beyond rows / width)
 __device__ __forceinline__ bf16x8 rowfrag(const bf16* base, long row, long rows, int width, int lg) {
     if (row >= rows || 8 * lg >= width) return zero8();
@@ -75,36 +98,42 @@ __global__ __launch_bounds__(256) void nl_attn_fwd_kernel(const bf16* __restrict
     f32x4 o[DV / 16];
 #pragma unroll
     for (int nt = 0; nt < DV / 16; ++nt) o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // operands of key chunk c+1 (K fragments, the V rows staged for the transposed reads) are requested into registers
-    // before chunk c is computed
+    // These kernels are bound by VALU ISSUE (~45 VALU instructions per MFMA), and close to half of those instructions were register
+    // copies of the software pipeline (`cur = next`) and, here, AGPR <-> VGPR moves of the output accumulators for the per-chunk
+    // softmax rescale.  So: two register sets used in turn by a loop unrolled twice (no copies); loads unconditional with rows clamped
+    // to the last key (keys >= Lk are masked out of the softmax, a clamped row only ever meets p = 0) -- under per-lane conditions or
+    // behind a branch the compiler cannot count the younger loads and drains the counter; and the rescale of o / l only when some
+    // row's maximum has grown by more than RESCALE_T since its reference was set (wave-uniform branch): p = exp(s - m_ref) stays
+    // below e^RESCALE_T, exact in fp32 and harmless in the bf16 pack.
     constexpr int SV = (AT_CH * DV / 8 + 255) / 256;               // V staging chunks per thread
-    bf16x8 kf_n[2], sv_n[SV];
-    auto prefetch = [&](int kc) {
+    constexpr float RESCALE_T = 8.f;
+    struct Pre { bf16x8 kf[2], sv[SV]; };
+    Pre pa_, pb_;
+    const int kcol = min(8 * lg, dqk - 8);
+    const bool kpad = 8 * lg >= dqk;
+    auto prefetch = [&](int kc, Pre& P) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) kf_n[t] = rowfrag(Kn, kc + 16 * t + lr, Lk, dqk, lg);
+        for (int t = 0; t < 2; ++t) P.kf[t] = *(const bf16x8*)(Kn + min((long)kc + 16 * t + lr, (long)Lk - 1) * dqk + kcol);
 #pragma unroll
         for (int j = 0; j < SV; ++j) {
-            const int idx = threadIdx.x + j * 256;
+            const int idx = min((int)threadIdx.x + j * 256, AT_CH * (DV / 8) - 1);
             const int r = idx / (DV / 8), c = idx - r * (DV / 8);
-            sv_n[j] = zero8();
-            if (idx < AT_CH * (DV / 8) && kc + r < Lk) sv_n[j] = *(const bf16x8*)(Vn + (long)(kc + r) * DV + c * 8);
+            P.sv[j] = *(const bf16x8*)(Vn + min((long)kc + r, (long)Lk - 1) * DV + c * 8);
         }
     };
-    prefetch(0);
-    for (int kc = 0; kc < Lk; kc += AT_CH) {
-        const bf16x8 kf0 = kf_n[0], kf1 = kf_n[1];
+    auto chunk = [&](int kc, Pre& P) {
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < SV; ++j) {
             const int idx = threadIdx.x + j * 256;
             const int r = idx / (DV / 8), c = idx - r * (DV / 8);
-            if (idx < AT_CH * (DV / 8)) *(bf16x8*)(vlds + r * DV + c * 8) = sv_n[j];
+            if (idx < AT_CH * (DV / 8)) *(bf16x8*)(vlds + r * DV + c * 8) = P.sv[j];
         }
         __syncthreads();
-        if (kc + AT_CH < Lk) prefetch(kc + AT_CH);
         f32x4 s[2];                                                // S^T tile t: rows = keys kc+16t.., cols = queries
-        s[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        s[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        s[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kpad ? zero8() : P.kf[0], qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        s[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kpad ? zero8() : P.kf[1], qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        prefetch(kc + 2 * AT_CH, P);                               // (past the end: clamped, never consumed)
         float cm = -1e30f;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -114,31 +143,41 @@ __global__ __launch_bounds__(256) void nl_attn_fwd_kernel(const bf16* __restrict
                 cm = fmaxf(cm, s[t][r]);
             }
         cm = fmaxf(cm, __shfl_xor(cm, 16, 64));
-        cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
-        const float mn = fmaxf(m, cm);
-        const float alpha = __expf(m - mn);
+        cm = fmaxf(cm, __shfl_xor(cm, 32, 64));                    // chunk maximum of query lr
+        if (__any(cm > m + RESCALE_T)) {                           // rare after the first chunk
+            const float mn = fmaxf(m, cm);
+            const float alpha = __expf(m - mn);
+            l *= alpha;
+            m = mn;
+            float ar[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, 4 * lg + r, 64);   // output rows of this lane are queries 4g+r
+#pragma unroll
+            for (int nt = 0; nt < DV / 16; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[nt][r] *= ar[r];
+        }
         float cs = 0.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                s[t][r] = __expf(s[t][r] - mn);
+                s[t][r] = (kc + 16 * t + 4 * lg + r >= Lk) ? 0.f : __expf(s[t][r] - m);
                 cs += s[t][r];
             }
         cs += __shfl_xor(cs, 16, 64);
         cs += __shfl_xor(cs, 32, 64);
-        l = l * alpha + cs;
-        m = mn;
-        float ar[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, 4 * lg + r, 64);   // output rows of this lane are queries 4g+r
+        l += cs;
         const bf16x8 pa = pack2(s[0], s[1]);                       // A operand: [query lr][k-slot (g,j) = key pi(g,j)]
 #pragma unroll
-        for (int nt = 0; nt < DV / 16; ++nt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[nt][r] *= ar[r];
+        for (int nt = 0; nt < DV / 16; ++nt)
             o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, trfrag(vlds, DV, nt * 16, lr, lg), o[nt], 0, 0, 0);
-        }
+    };
+    prefetch(0, pa_);
+    prefetch(AT_CH, pb_);
+    for (int kc = 0; kc < Lk; kc += 2 * AT_CH) {
+        chunk(kc, pa_);
+        chunk(kc + AT_CH, pb_);     // unconditional: an odd chunk count runs one fully masked chunk (p = 0 against clamped rows)
     }
     if (lg == 0 && q0 + lr < Lq) LSE[n * Lq + q0 + lr] = m + __logf(l);
     float il[4];
@@ -157,7 +196,7 @@ __global__ __launch_bounds__(256) void nl_attn_fwd_kernel(const bf16* __restrict
 // backward, query side: delta[q] = dO[q].O[q];  dQ[q] = sum_k dS[q,k] K[k],  dS = P (dP - delta), dP = dO V^T.
 // ------------------------------------------------------------------------------------------------
 template <int DV>
-__global__ __launch_bounds__(256) void nl_attn_bwd_q_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+__global__ __launch_bounds__(256, 3) void nl_attn_bwd_q_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                             const bf16* __restrict__ V, const bf16* __restrict__ O,
                                                             const bf16* __restrict__ dO, const float* __restrict__ LSE,
                                                             float* __restrict__ delta, bf16* __restrict__ dQ, int Lq, int Lk, int dqk) {
@@ -187,57 +226,57 @@ __global__ __launch_bounds__(256) void nl_attn_bwd_q_kernel(const bf16* __restri
     const float lse = (q0 + lr < Lq) ? LSE[n * Lq + q0 + lr] : 0.f;
     if (lg == 0 && q0 + lr < Lq) delta[n * Lq + q0 + lr] = dl;
     f32x4 dq[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-    // operands of key chunk c+1 (A fragments of K and V, the K rows staged for the transposed reads) are requested
-    // into registers before chunk c is computed
-    bf16x8 kf_n[2], vf_n[2][DV / 32], sk_n;
-    auto prefetch = [&](int kc) {
+    // two register sets used in turn, unconditional clamped loads (see the forward kernel): the operands of key chunk c+1 are in
+    // flight while chunk c is computed, and nothing is copied
+    struct Pre { bf16x8 kf[2], vf[2][DV / 32], sk; };
+    Pre pa_, pb_;
+    const int kcol = min(8 * lg, dqk - 8);
+    const bool kpad = 8 * lg >= dqk;
+    const int sr = (threadIdx.x >> 2) & (AT_CH - 1), sc = threadIdx.x & 3;
+    const int scol = min(sc * 8, dqk - 8);
+    auto prefetch = [&](int kc, Pre& P) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const long krow = kc + 16 * t + lr;
-            kf_n[t] = rowfrag(Kn, krow, Lk, dqk, lg);
+            const long krow = min((long)kc + 16 * t + lr, (long)Lk - 1);
+            P.kf[t] = *(const bf16x8*)(Kn + krow * dqk + kcol);
 #pragma unroll
-            for (int s = 0; s < DV / 32; ++s) {
-                vf_n[t][s] = zero8();
-                if (krow < Lk) vf_n[t][s] = *(const bf16x8*)(Vn + krow * DV + 32 * s + 8 * lg);
-            }
+            for (int s = 0; s < DV / 32; ++s) P.vf[t][s] = *(const bf16x8*)(Vn + krow * DV + 32 * s + 8 * lg);
         }
-        const int r = threadIdx.x >> 2, c = threadIdx.x & 3;
-        sk_n = zero8();
-        if (threadIdx.x < AT_CH * 4 && kc + r < Lk && c * 8 < dqk) sk_n = *(const bf16x8*)(Kn + (long)(kc + r) * dqk + c * 8);
+        P.sk = *(const bf16x8*)(Kn + min((long)kc + sr, (long)Lk - 1) * dqk + scol);
     };
-    prefetch(0);
-    for (int kc = 0; kc < Lk; kc += AT_CH) {
-        bf16x8 kfc[2], vfc[2][DV / 32];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            kfc[t] = kf_n[t];
-#pragma unroll
-            for (int s = 0; s < DV / 32; ++s) vfc[t][s] = vf_n[t][s];
-        }
+    auto chunk = [&](int kc, Pre& P) {
         __syncthreads();
-        // K chunk [32 keys][32] (zero padded beyond dqk) for the transposed reads of the dQ product
-        if (threadIdx.x < AT_CH * 4) *(bf16x8*)(klds + (threadIdx.x >> 2) * 32 + (threadIdx.x & 3) * 8) = sk_n;
+        // K chunk [32 keys][32] (zero beyond Lk / dqk) for the transposed reads of the dQ product
+        if (threadIdx.x < AT_CH * 4) *(bf16x8*)(klds + sr * 32 + sc * 8) = (kc + sr < Lk && sc * 8 < dqk) ? P.sk : zero8();
         __syncthreads();
-        if (kc + AT_CH < Lk) prefetch(kc + AT_CH);
         f32x4 p[2], dp[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            p[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfc[t], qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            p[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kpad ? zero8() : P.kf[t], qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             dp[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < DV / 32; ++s)                      // dP^T tile: rows = keys, cols = queries
-                dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfc[t][s], dof[s], dp[t], 0, 0, 0);
+                dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(P.vf[t][s], dof[s], dp[t], 0, 0, 0);
+        }
+        prefetch(kc + 2 * AT_CH, P);                               // the set is free again (past the end: clamped, never consumed)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const bool ok = kc + 16 * t + 4 * lg + r < Lk;
                 const float pr = ok ? __expf(p[t][r] - lse) : 0.f;
-                p[t][r] = pr * (dp[t][r] - dl);                    // dS[query lr][key]
+                p[t][r] = ok ? pr * (dp[t][r] - dl) : 0.f;         // dS[query lr][key]
             }
-        }
         const bf16x8 dsa = pack2(p[0], p[1]);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
             dq[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsa, trfrag(klds, 32, nt * 16, lr, lg), dq[nt], 0, 0, 0);
+    };
+    prefetch(0, pa_);
+    prefetch(AT_CH, pb_);
+    for (int kc = 0; kc < Lk; kc += 2 * AT_CH) {
+        chunk(kc, pa_);
+        chunk(kc + AT_CH, pb_);     // unconditional (fully masked when past the end)
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -252,8 +291,8 @@ __global__ __launch_bounds__(256) void nl_attn_bwd_q_kernel(const bf16* __restri
 // ------------------------------------------------------------------------------------------------
 // backward, key side: dV[k] = sum_q P[q,k] dO[q],  dK[k] = sum_q dS[q,k] Q[q].  4 waves x 16 keys, queries streamed.
 // ------------------------------------------------------------------------------------------------
-template <int DV>
-__global__ __launch_bounds__(256) void nl_attn_bwd_k_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+template <int DV, bool LQ4>        // LQ4: Lq % 4 == 0 -- LSE / delta of the 4 rows of a lane come as one 16-byte load
+__global__ __launch_bounds__(256, 2) void nl_attn_bwd_k_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                             const bf16* __restrict__ V, const bf16* __restrict__ dO,
                                                             const float* __restrict__ LSE, const float* __restrict__ delta,
                                                             bf16* __restrict__ dK, bf16* __restrict__ dV, int Lq, int Lk, int dqk) {
@@ -278,94 +317,93 @@ __global__ __launch_bounds__(256) void nl_attn_bwd_k_kernel(const bf16* __restri
 #pragma unroll
     for (int nt = 0; nt < DV / 16; ++nt) dv[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     dk[0] = dk[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // The 480 blocks of this kernel cannot hide memory latency behind each other (< 2 per CU), so every global operand of
-    // chunk c+1 -- the A fragments of Q and dO, the rows staged into LDS for the transposed reads, LSE and delta -- is
-    // requested into registers before chunk c is computed.
+    // This kernel was bound by the L2 -> CU path, not by arithmetic or latency: every wave fetched the A fragments of Q and dO of
+    // every query chunk straight from global memory (16 rows x 64 bytes per instruction, the same fragments in all four waves, on
+    // top of the rows staged for the transposed reads: 68 KB per block and chunk, 3.1 GB per launch; switching the in-loop loads off
+    // took it from 235 to 160 us, nothing else moved it).  Now a chunk crosses L2 -> LDS ONCE in full rows (10 KB) and all fragments
+    // -- A operands with ds_read_b128, B operands with transposed reads -- come from swizzled LDS tiles.  Two register sets used in
+    // turn by a loop unrolled twice, unconditional clamped loads (see the forward kernel).
     constexpr int SD = (AT_CH * DV / 8) / 256;                     // dO staging chunks per thread (1 / 1 / 2 for DV 32 / 64 / 128)
     static_assert(SD >= 1 || DV == 32, "staging split");
     constexpr int SDN = SD > 0 ? SD : 1;
-    bf16x8 qa_n[2], da_n[2][DV / 32], sdo_n[SDN], sq_n;
-    float lse_n[2][4], dlt_n[2][4];
-    auto prefetch = [&](int qc) {
+    constexpr int CPR = DV / 8;                                    // 16-byte chunks per dO row
+    struct Pre { bf16x8 sdo[SDN], sq; f32x4 lse[2], dlt[2]; };
+    Pre pa_, pb_;
+    const int sr = (threadIdx.x >> 2) & (AT_CH - 1), sc = threadIdx.x & 3;
+    const int scol = min(sc * 8, dqk - 8);
+    const float* LSEn = LSE + n * Lq;
+    const float* DLTn = delta + n * Lq;
+    auto prefetch = [&](int qc, Pre& P) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const long qrow = qc + 16 * t + lr;
-            qa_n[t] = rowfrag(Qn, qrow, Lq, dqk, lg);
+            const long qb = (long)qc + 16 * t + 4 * lg;
+            if (LQ4) {
+                const long q4 = min(qb, (long)Lq - 4);
+                P.lse[t] = *(const f32x4*)(LSEn + q4);
+                P.dlt[t] = *(const f32x4*)(DLTn + q4);
+            } else {
 #pragma unroll
-            for (int s = 0; s < DV / 32; ++s) {
-                da_n[t][s] = zero8();
-                if (qrow < Lq) da_n[t][s] = *(const bf16x8*)(dOn + qrow * DV + 32 * s + 8 * lg);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long q = qc + 16 * t + 4 * lg + r;
-                lse_n[t][r] = (q < Lq) ? LSE[n * Lq + q] : 0.f;
-                dlt_n[t][r] = (q < Lq) ? delta[n * Lq + q] : 0.f;
+                for (int r = 0; r < 4; ++r) {
+                    const long q = min(qb + r, (long)Lq - 1);
+                    P.lse[t][r] = LSEn[q];
+                    P.dlt[t][r] = DLTn[q];
+                }
             }
         }
 #pragma unroll
         for (int j = 0; j < SDN; ++j) {
-            const int idx = threadIdx.x + j * 256;
-            const int r = idx / (DV / 8), c = idx - r * (DV / 8);
-            sdo_n[j] = zero8();
-            if (idx < AT_CH * (DV / 8) && qc + r < Lq) sdo_n[j] = *(const bf16x8*)(dOn + (long)(qc + r) * DV + c * 8);
+            const int idx = min((int)threadIdx.x + j * 256, AT_CH * CPR - 1);
+            const int r = idx / CPR, c = idx - r * CPR;
+            P.sdo[j] = *(const bf16x8*)(dOn + min((long)qc + r, (long)Lq - 1) * DV + c * 8);
         }
-        {
-            const int r = threadIdx.x >> 2, c = threadIdx.x & 3;
-            sq_n = zero8();
-            if (threadIdx.x < AT_CH * 4 && qc + r < Lq && c * 8 < dqk) sq_n = *(const bf16x8*)(Qn + (long)(qc + r) * dqk + c * 8);
-        }
+        P.sq = *(const bf16x8*)(Qn + min((long)qc + sr, (long)Lq - 1) * dqk + scol);
     };
-    prefetch(0);
-    for (int qc = 0; qc < Lq; qc += AT_CH) {
-        bf16x8 qa[2], da[2][DV / 32];
-        float lse[2][4], dlt[2][4];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            qa[t] = qa_n[t];
-#pragma unroll
-            for (int s = 0; s < DV / 32; ++s) da[t][s] = da_n[t][s];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                lse[t][r] = lse_n[t][r];
-                dlt[t][r] = dlt_n[t][r];
-            }
-        }
-        __syncthreads();                                           // the previous chunk's transposed reads are done
+    auto chunk = [&](int qc, Pre& P) {
+        __syncthreads();                                           // the previous chunk's LDS reads are done
 #pragma unroll
         for (int j = 0; j < SDN; ++j) {
             const int idx = threadIdx.x + j * 256;
-            const int r = idx / (DV / 8), c = idx - r * (DV / 8);
-            if (idx < AT_CH * (DV / 8)) *(bf16x8*)(dolds + r * DV + c * 8) = sdo_n[j];
+            const int r = idx / CPR, c = idx - r * CPR;
+            if (idx < AT_CH * CPR) *(bf16x8*)(dolds + swz_off<DV>(r, c)) = (qc + r < Lq) ? P.sdo[j] : zero8();
         }
-        if (threadIdx.x < AT_CH * 4) *(bf16x8*)(qlds + (threadIdx.x >> 2) * 32 + (threadIdx.x & 3) * 8) = sq_n;
+        if (threadIdx.x < AT_CH * 4) *(bf16x8*)(qlds + swz_off<32>(sr, sc)) = (qc + sr < Lq && sc * 8 < dqk) ? P.sq : zero8();
         __syncthreads();
-        if (qc + AT_CH < Lq) prefetch(qc + AT_CH);                 // in flight during this chunk's MFMAs
+        const f32x4 lse0 = P.lse[0], lse1 = P.lse[1], dlt0 = P.dlt[0], dlt1 = P.dlt[1];
+        prefetch(qc + 2 * AT_CH, P);                               // the set is free again (past the end: clamped, never consumed)
         f32x4 p[2], ds[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {                              // tile t: rows = queries qc+16t.., cols = keys
-            p[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[t], kf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            const int row = 16 * t + lr;
+            const bf16x8 qa = *(const bf16x8*)(qlds + swz_off<32>(row, lg));            // [query lr][d 8g..] (zero beyond dqk)
+            p[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             ds[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < DV / 32; ++s)                      // dP tile: rows = queries, cols = keys
-                ds[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da[t][s], vf[s], ds[t], 0, 0, 0);
+                ds[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(dolds + swz_off<DV>(row, 4 * s + lg)), vf[s], ds[t], 0, 0, 0);
+            const f32x4 lse = t ? lse1 : lse0, dlt = t ? dlt1 : dlt0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const long q = qc + 16 * t + 4 * lg + r;           // query (row) of this accumulator element
                 const bool ok = q < Lq && k0 + lr < Lk;
-                const float pr = ok ? __expf(p[t][r] - lse[t][r]) : 0.f;
+                const float pr = ok ? __expf(p[t][r] - lse[r]) : 0.f;
                 p[t][r] = pr;                                      // P[q][key lr]
-                ds[t][r] = pr * (ds[t][r] - (ok ? dlt[t][r] : 0.f));   // dS[q][key lr]
+                ds[t][r] = ok ? pr * (ds[t][r] - dlt[r]) : 0.f;    // dS[q][key lr]
             }
         }
         const bf16x8 pa = pack2(p[0], p[1]);                       // A: [key lr][k-slot (g,j) = query pi(g,j)]
         const bf16x8 dsa = pack2(ds[0], ds[1]);
 #pragma unroll
         for (int nt = 0; nt < DV / 16; ++nt)
-            dv[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, trfrag(dolds, DV, nt * 16, lr, lg), dv[nt], 0, 0, 0);
+            dv[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, trfrag_swz<DV>(dolds, nt * 16, lr, lg), dv[nt], 0, 0, 0);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
-            dk[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsa, trfrag(qlds, 32, nt * 16, lr, lg), dk[nt], 0, 0, 0);
+            dk[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsa, trfrag_swz<32>(qlds, nt * 16, lr, lg), dk[nt], 0, 0, 0);
+    };
+    prefetch(0, pa_);
+    prefetch(AT_CH, pb_);
+    for (int qc = 0; qc < Lq; qc += 2 * AT_CH) {
+        chunk(qc, pa_);
+        chunk(qc + AT_CH, pb_);     // unconditional (fully masked when past the end)
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -407,8 +445,12 @@ extern "C" int ieagan_nl_attention_bwd(const void* Q, const void* K, const void*
 #define L(D)                                                                                                                   \
     hipLaunchKernelGGL((nl_attn_bwd_q_kernel<D>), gq, dim3(256), 0, st, (const bf16*)Q, (const bf16*)K, (const bf16*)V,       \
                        (const bf16*)O, (const bf16*)dO, LSE, delta, (bf16*)dQ, Lq, Lk, dqk);                                   \
-    hipLaunchKernelGGL((nl_attn_bwd_k_kernel<D>), gk, dim3(256), 0, st, (const bf16*)Q, (const bf16*)K, (const bf16*)V,       \
-                       (const bf16*)dO, LSE, (const float*)delta, (bf16*)dK, (bf16*)dV, Lq, Lk, dqk)
+    if ((Lq & 3) == 0)                                                                                                         \
+        hipLaunchKernelGGL((nl_attn_bwd_k_kernel<D, true>), gk, dim3(256), 0, st, (const bf16*)Q, (const bf16*)K, (const bf16*)V, \
+                           (const bf16*)dO, LSE, (const float*)delta, (bf16*)dK, (bf16*)dV, Lq, Lk, dqk);                        \
+    else                                                                                                                       \
+        hipLaunchKernelGGL((nl_attn_bwd_k_kernel<D, false>), gk, dim3(256), 0, st, (const bf16*)Q, (const bf16*)K, (const bf16*)V, \
+                           (const bf16*)dO, LSE, (const float*)delta, (bf16*)dK, (bf16*)dV, Lq, Lk, dqk)
     if (dv == 32) { L(32); } else if (dv == 64) { L(64); } else { L(128); }
 #undef L
     CHECK_LAUNCH("nl_attention_bwd");

@@ -625,7 +625,7 @@ def test_adam_and_ema(dev, golden_dir):
     close(t, exp, 1e-6, "ema")
 
 
-@pytest.mark.parametrize("N,Lq,Lk,dqk,dv", [(2, 256, 64, 8, 32), (3, 192, 96, 32, 128), (2, 150, 70, 16, 64)])
+@pytest.mark.parametrize("N,Lq,Lk,dqk,dv", [(2, 256, 64, 8, 32), (3, 192, 96, 32, 128), (2, 150, 70, 16, 64), (2, 3072, 768, 32, 128), (1, 100, 33, 24, 128)])
 def test_nl_attention_forward_backward(dev, N, Lq, Lk, dqk, dv):
     """Streaming-softmax attention core vs softmax(QK^T)V in fp32 (incl. ragged Lq / Lk tails)."""
     import ops
