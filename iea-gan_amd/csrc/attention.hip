@@ -86,6 +86,7 @@ __global__ __launch_bounds__(256) void nl_attn_fwd_kernel(const bf16* __restrict
                                                           const bf16* __restrict__ V, bf16* __restrict__ O, float* __restrict__ LSE,
                                                           int Lq, int Lk, int dqk) {
     __shared__ __attribute__((aligned(16))) bf16 vlds[AT_CH * DV];
+    __shared__ __attribute__((aligned(16))) bf16 klds[AT_CH * 32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 15, lg = lane >> 4;
     const long n = blockIdx.y;
@@ -105,35 +106,36 @@ __global__ __launch_bounds__(256) void nl_attn_fwd_kernel(const bf16* __restrict
     // behind a branch the compiler cannot count the younger loads and drains the counter; and the rescale of o / l only when some
     // row's maximum has grown by more than RESCALE_T since its reference was set (wave-uniform branch): p = exp(s - m_ref) stays
     // below e^RESCALE_T, exact in fp32 and harmless in the bf16 pack.
-    constexpr int SV = (AT_CH * DV / 8 + 255) / 256;               // V staging chunks per thread
+    constexpr int CPR = DV / 8;                                    // 16-byte chunks per V row
+    constexpr int SV = (AT_CH * CPR + 255) / 256;                  // V staging chunks per thread
     constexpr float RESCALE_T = 8.f;
-    struct Pre { bf16x8 kf[2], sv[SV]; };
+    struct Pre { bf16x8 sk, sv[SV]; };
     Pre pa_, pb_;
-    const int kcol = min(8 * lg, dqk - 8);
-    const bool kpad = 8 * lg >= dqk;
-    auto prefetch = [&](int kc, Pre& P) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) P.kf[t] = *(const bf16x8*)(Kn + min((long)kc + 16 * t + lr, (long)Lk - 1) * dqk + kcol);
+    const int sr = (threadIdx.x >> 2) & (AT_CH - 1), sc = threadIdx.x & 3;
+    const int scol = min(sc * 8, dqk - 8);
+    auto prefetch = [&](int kc, Pre& P) {                          // a key chunk crosses L2 -> LDS once, in full rows
+        P.sk = *(const bf16x8*)(Kn + min((long)kc + sr, (long)Lk - 1) * dqk + scol);
 #pragma unroll
         for (int j = 0; j < SV; ++j) {
-            const int idx = min((int)threadIdx.x + j * 256, AT_CH * (DV / 8) - 1);
-            const int r = idx / (DV / 8), c = idx - r * (DV / 8);
+            const int idx = min((int)threadIdx.x + j * 256, AT_CH * CPR - 1);
+            const int r = idx / CPR, c = idx - r * CPR;
             P.sv[j] = *(const bf16x8*)(Vn + min((long)kc + r, (long)Lk - 1) * DV + c * 8);
         }
     };
     auto chunk = [&](int kc, Pre& P) {
         __syncthreads();
+        if (threadIdx.x < AT_CH * 4) *(bf16x8*)(klds + swz_off<32>(sr, sc)) = (sc * 8 < dqk) ? P.sk : zero8();
 #pragma unroll
         for (int j = 0; j < SV; ++j) {
             const int idx = threadIdx.x + j * 256;
-            const int r = idx / (DV / 8), c = idx - r * (DV / 8);
-            if (idx < AT_CH * (DV / 8)) *(bf16x8*)(vlds + r * DV + c * 8) = P.sv[j];
+            const int r = idx / CPR, c = idx - r * CPR;
+            if (idx < AT_CH * CPR) *(bf16x8*)(vlds + swz_off<DV>(r, c)) = P.sv[j];
         }
         __syncthreads();
-        f32x4 s[2];                                                // S^T tile t: rows = keys kc+16t.., cols = queries
-        s[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kpad ? zero8() : P.kf[0], qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        s[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kpad ? zero8() : P.kf[1], qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         prefetch(kc + 2 * AT_CH, P);                               // (past the end: clamped, never consumed)
+        f32x4 s[2];                                                // S^T tile t: rows = keys kc+16t.., cols = queries
+        s[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(klds + swz_off<32>(lr, lg)), qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        s[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(klds + swz_off<32>(16 + lr, lg)), qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         float cm = -1e30f;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(256) void nl_attn_fwd_kernel(const bf16* __restrict
         const bf16x8 pa = pack2(s[0], s[1]);                       // A operand: [query lr][k-slot (g,j) = key pi(g,j)]
 #pragma unroll
         for (int nt = 0; nt < DV / 16; ++nt)
-            o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, trfrag(vlds, DV, nt * 16, lr, lg), o[nt], 0, 0, 0);
+            o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa, trfrag_swz<DV>(vlds, nt * 16, lr, lg), o[nt], 0, 0, 0);
     };
     prefetch(0, pa_);
     prefetch(AT_CH, pb_);
@@ -196,11 +198,12 @@ __global__ __launch_bounds__(256) void nl_attn_fwd_kernel(const bf16* __restrict
 // backward, query side: delta[q] = dO[q].O[q];  dQ[q] = sum_k dS[q,k] K[k],  dS = P (dP - delta), dP = dO V^T.
 // ------------------------------------------------------------------------------------------------
 template <int DV>
-__global__ __launch_bounds__(256, 3) void nl_attn_bwd_q_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+__global__ __launch_bounds__(256) void nl_attn_bwd_q_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                             const bf16* __restrict__ V, const bf16* __restrict__ O,
                                                             const bf16* __restrict__ dO, const float* __restrict__ LSE,
                                                             float* __restrict__ delta, bf16* __restrict__ dQ, int Lq, int Lk, int dqk) {
     __shared__ __attribute__((aligned(16))) bf16 klds[AT_CH * 32];
+    __shared__ __attribute__((aligned(16))) bf16 vlds[AT_CH * DV];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 15, lg = lane >> 4;
     const long n = blockIdx.y;
@@ -226,51 +229,57 @@ __global__ __launch_bounds__(256, 3) void nl_attn_bwd_q_kernel(const bf16* __res
     const float lse = (q0 + lr < Lq) ? LSE[n * Lq + q0 + lr] : 0.f;
     if (lg == 0 && q0 + lr < Lq) delta[n * Lq + q0 + lr] = dl;
     f32x4 dq[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-    // two register sets used in turn, unconditional clamped loads (see the forward kernel): the operands of key chunk c+1 are in
-    // flight while chunk c is computed, and nothing is copied
-    struct Pre { bf16x8 kf[2], vf[2][DV / 32], sk; };
+    // A key chunk crosses L2 -> LDS once in full rows (K 2 KB, V 8 KB) and every fragment -- the A operands of S and dP with
+    // ds_read_b128, the B operand of dQ with transposed reads -- comes from the swizzled LDS tiles (see the key-side kernel: fragment-
+    // shaped global loads, repeated by all four waves, were what bound these kernels).  Two register sets used in turn,
+    // unconditional clamped loads (see the forward kernel).
+    constexpr int CPR = DV / 8;                                    // 16-byte chunks per V row
+    constexpr int SV = (AT_CH * CPR + 255) / 256;                  // V staging chunks per thread
+    struct Pre { bf16x8 sk, sv[SV]; };
     Pre pa_, pb_;
-    const int kcol = min(8 * lg, dqk - 8);
-    const bool kpad = 8 * lg >= dqk;
     const int sr = (threadIdx.x >> 2) & (AT_CH - 1), sc = threadIdx.x & 3;
     const int scol = min(sc * 8, dqk - 8);
     auto prefetch = [&](int kc, Pre& P) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const long krow = min((long)kc + 16 * t + lr, (long)Lk - 1);
-            P.kf[t] = *(const bf16x8*)(Kn + krow * dqk + kcol);
-#pragma unroll
-            for (int s = 0; s < DV / 32; ++s) P.vf[t][s] = *(const bf16x8*)(Vn + krow * DV + 32 * s + 8 * lg);
-        }
         P.sk = *(const bf16x8*)(Kn + min((long)kc + sr, (long)Lk - 1) * dqk + scol);
+#pragma unroll
+        for (int j = 0; j < SV; ++j) {
+            const int idx = min((int)threadIdx.x + j * 256, AT_CH * CPR - 1);
+            const int r = idx / CPR, c = idx - r * CPR;
+            P.sv[j] = *(const bf16x8*)(Vn + min((long)kc + r, (long)Lk - 1) * DV + c * 8);
+        }
     };
     auto chunk = [&](int kc, Pre& P) {
         __syncthreads();
-        // K chunk [32 keys][32] (zero beyond Lk / dqk) for the transposed reads of the dQ product
-        if (threadIdx.x < AT_CH * 4) *(bf16x8*)(klds + sr * 32 + sc * 8) = (kc + sr < Lk && sc * 8 < dqk) ? P.sk : zero8();
+        // K chunk [32 keys][32] (zero beyond Lk / dqk) and V chunk [32 keys][DV], swizzled
+        if (threadIdx.x < AT_CH * 4) *(bf16x8*)(klds + swz_off<32>(sr, sc)) = (kc + sr < Lk && sc * 8 < dqk) ? P.sk : zero8();
+#pragma unroll
+        for (int j = 0; j < SV; ++j) {
+            const int idx = threadIdx.x + j * 256;
+            const int r = idx / CPR, c = idx - r * CPR;
+            if (idx < AT_CH * CPR) *(bf16x8*)(vlds + swz_off<DV>(r, c)) = P.sv[j];      // (rows beyond Lk: clamped copies, masked below)
+        }
         __syncthreads();
+        prefetch(kc + 2 * AT_CH, P);                               // the set is free again (past the end: clamped, never consumed)
         f32x4 p[2], dp[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            p[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kpad ? zero8() : P.kf[t], qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            const int row = 16 * t + lr;
+            p[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(klds + swz_off<32>(row, lg)), qf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             dp[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < DV / 32; ++s)                      // dP^T tile: rows = keys, cols = queries
-                dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(P.vf[t][s], dof[s], dp[t], 0, 0, 0);
-        }
-        prefetch(kc + 2 * AT_CH, P);                               // the set is free again (past the end: clamped, never consumed)
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
+                dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(vlds + swz_off<DV>(row, 4 * s + lg)), dof[s], dp[t], 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const bool ok = kc + 16 * t + 4 * lg + r < Lk;
                 const float pr = ok ? __expf(p[t][r] - lse) : 0.f;
                 p[t][r] = ok ? pr * (dp[t][r] - dl) : 0.f;         // dS[query lr][key]
             }
+        }
         const bf16x8 dsa = pack2(p[0], p[1]);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
-            dq[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsa, trfrag(klds, 32, nt * 16, lr, lg), dq[nt], 0, 0, 0);
+            dq[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dsa, trfrag_swz<32>(klds, nt * 16, lr, lg), dq[nt], 0, 0, 0);
     };
     prefetch(0, pa_);
     prefetch(AT_CH, pb_);
