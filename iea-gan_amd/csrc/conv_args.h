@@ -16,3 +16,4 @@ int conv_wgrad_launch(const WgradArgs& a, hipStream_t st, int use_tr);
 int conv3x3_lds_launch(const ConvArgs& a, hipStream_t st);       // 1 = launched, 0 = not applicable (caller falls back to conv3x3_halo), < 0 = error
 int conv3x3_ws_launch(const ConvArgs& a, hipStream_t st);         // 1 = launched, 0 = not applicable (caller falls back to conv3x3_halo)
 int conv1x1_stream_launch(const ConvArgs& a, hipStream_t st);     // 1 = launched, 0 = not applicable (caller falls back to conv_gather)
+int conv1x1_tile_launch(const ConvArgs& a, hipStream_t st);       // 1 = launched, 0 = not applicable (caller falls back to conv_gather)

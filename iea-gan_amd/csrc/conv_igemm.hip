@@ -588,9 +588,13 @@ int conv_gather_launch(const ConvArgs& a, hipStream_t st) {
         if (a.src.rs == 0) {
             // large maps: the streaming kernel (prefetched operands, weights in registers); otherwise one tile per block
             if (!(a.flags & IEAGAN_CONV_FORCE_GATHER) && conv1x1_stream_launch(a, st)) rc = 0;
+            else if (!(a.flags & IEAGAN_CONV_FORCE_GATHER) && conv1x1_tile_launch(a, st)) rc = 0;      // operands through LDS in full rows
             else rc = launch_gather_pro<1, 0>(a, st);
         }
-        else if (a.src.rs == 2) rc = launch_gather_pro<1, 2>(a, st);
+        else if (a.src.rs == 2) {
+            if (!(a.flags & IEAGAN_CONV_FORCE_GATHER) && conv1x1_tile_launch(a, st)) rc = 0;
+            else rc = launch_gather_pro<1, 2>(a, st);
+        }
         else { ieagan_set_error("conv: 1x1 with upsampled source is not instantiated"); return IEAGAN_EINVAL; }
     }
     CHECK_LAUNCH("conv_forward");
