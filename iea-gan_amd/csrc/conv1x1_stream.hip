@@ -132,7 +132,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs a, int 
             __syncthreads();
         }
         const long wbase = gbase + wave * (MT * 16);
-        __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): group g's operands (requested one iteration ago) have landed
+        // group g's operands (requested one iteration ago) have landed.  NOT vmcnt(0): on gfx9 the counter also holds the STORES of
+        // group g-1, which were issued after those loads -- draining them put the write latency of every group on the critical path
+        // of the next one.  The EP * ITER store instructions of a group are always issued (whole groups only: HW % GP == 0).
+        __builtin_amdgcn_s_waitcnt(0x0F70 | (EP * ITER));
         if (g + 1 < g1) {
             load_A(g + 1, nxt);
             load_epi(g + 1, pm_n, pr_n);

@@ -15,7 +15,10 @@
 #define WS_H 8
 #define WS_W 32
 
-template <bool AFF, bool RELU, int RS, int CIN, bool BNB, bool MPF, int NCW>
+// FULL: H % WS_H == 0 and W % WS_W == 0 -- every output pixel of every tile exists, so the epilogue's stores and the mask requests are
+// unconditional and the compiler can COUNT them: a consumer then waits for the mask chunks of tile r only, not (vmcnt(0)) for the
+// stores of tile r-1 that were issued behind them.
+template <bool AFF, bool RELU, int RS, int CIN, bool BNB, bool MPF, int NCW, bool FULL>
 __global__ __launch_bounds__((NCW + 4) * 64, (NCW == 4 ? 4 : 3)) void conv3x3_ws_kernel(ConvArgs a, int tiles_w, int tiles_h, int tpe, int tpb, int nblk, int bpe) {
     constexpr int NT = CIN / 16;
     constexpr int AW = WS_W + 2, AH = WS_H + 2;
@@ -77,14 +80,16 @@ __global__ __launch_bounds__((NCW + 4) * 64, (NCW == 4 ? 4 : 3)) void conv3x3_ws
             okmask = 0;
 #pragma unroll
             for (int j = 0; j < PF; ++j) {
-                const int idx = ptid + j * 256;
+                // UNCONDITIONAL loads (coordinates clamped into the image, the padding ring zeroed by okmask in store_tile): under a
+                // per-lane condition the compiler cannot count the younger loads of the other register set and drains the counter
+                // -- vmcnt(0) -- before every store_tile, which left ONE tile in flight instead of two
+                const int idx = min(ptid + j * 256, TOT - 1);
                 const int hp = idx / CH, cc = idx - hp * CH;
                 const int hh = h0 - 1 + hp / AW, ww = w0 - 1 + hp % AW;
-                if (idx < TOT && hh >= 0 && hh < H && ww >= 0 && ww < W) {
-                    const int sh_ = (RS == 1) ? (hh >> 1) : hh, sw_ = (RS == 1) ? (ww >> 1) : ww;
-                    raw[j] = *(const bf16x8*)((const bf16*)a.src.x + (((long)n * a.src.Hs + sh_) * a.src.Ws + sw_) * a.src.Cx + cc * 8);
-                    okmask |= 1u << j;
-                }
+                const int hc = min(max(hh, 0), H - 1), wc = min(max(ww, 0), W - 1);
+                const int sh_ = (RS == 1) ? (hc >> 1) : hc, sw_ = (RS == 1) ? (wc >> 1) : wc;
+                raw[j] = *(const bf16x8*)((const bf16*)a.src.x + (((long)n * a.src.Hs + sh_) * a.src.Ws + sw_) * a.src.Cx + cc * 8);
+                if (ptid + j * 256 < TOT && hh >= 0 && hh < H && ww >= 0 && ww < W) okmask |= 1u << j;
             }
         };
         auto store_tile = [&](int t, const bf16x8(&raw)[PF], unsigned okmask, char* dst) {
@@ -125,23 +130,30 @@ __global__ __launch_bounds__((NCW + 4) * 64, (NCW == 4 ? 4 : 3)) void conv3x3_ws
         };
         // produce step r (runs next to the consumers' tile r): tile r+1 -> the other halo buffer, then request tile r+3 into the
         // register set that has just been drained
+        // (requests past the block's last tile re-read that tile and are never stored: the request stays unconditional, and the loop is
+        //  unrolled by the two register sets instead of branching on the parity of r -- a branch or a join in front of a use makes
+        //  the compiler assume the youngest possible request and wait for everything in flight)
         auto produce = [&](int r, bf16x8(&raw)[PF], unsigned& okmask) {
             if (r + 1 < ntl) store_tile(t0 + r + 1, raw, okmask, halo0 + ((r + 1) & 1) * HALO_BYTES);
-            if (r + 3 < ntl) load_tile(t0 + r + 3, raw, okmask);
+            load_tile(t0 + min(r + 3, ntl - 1), raw, okmask);
         };
-        if (ntl > 0) {
-            load_tile(t0, rawA, okA);
-            store_tile(t0, rawA, okA, halo0);
-            if (ntl > 1) load_tile(t0 + 1, rawB, okB);        // set B: odd tiles
-            if (ntl > 2) load_tile(t0 + 2, rawA, okA);        // set A: even tiles
+        if (ntl <= 0) {                                       // (its own exit: no join in front of the loop below)
+            __syncthreads();
+            return;
         }
+        load_tile(t0, rawA, okA);
+        store_tile(t0, rawA, okA, halo0);
+        load_tile(t0 + min(1, ntl - 1), rawB, okB);           // set B: odd tiles
+        load_tile(t0 + min(2, ntl - 1), rawA, okA);           // set A: even tiles
         __syncthreads();
-        for (int r = 0; r < ntl; ++r) {
-            if (r & 1) produce(r, rawA, okA);       // tile r+1 is even -> set A
-            else produce(r, rawB, okB);
+        for (int r = 0; r < ntl; r += 2) {
+            produce(r, rawB, okB);                  // tile r+1 is odd -> set B
+            __syncthreads();
+            if (r + 1 >= ntl) break;
+            produce(r + 1, rawA, okA);              // tile r+2 is even -> set A
             __syncthreads();
         }
-        if (a.stats != nullptr && ntl > 0) __syncthreads();       // matches the block barrier inside stats_flush
+        if (a.stats != nullptr) __syncthreads();              // matches the block barrier inside stats_flush
         return;
     }
 
@@ -169,8 +181,12 @@ __global__ __launch_bounds__((NCW + 4) * 64, (NCW == 4 ? 4 : 3)) void conv3x3_ws
 #pragma unroll
             for (int it = 0; it < EIT; ++it) {
                 const int hh = h0 + RPW * wave + half, ww = w0 + (it * 64 + lane) / CPP;
-                mk[half * EIT + it] = zero8();
-                if (hh < H && ww < W) mk[half * EIT + it] = *(const bf16x8*)((const bf16*)a.mask + (((long)n * H + hh) * W + ww) * CIN + ecc * 8);
+                if (FULL) {
+                    mk[half * EIT + it] = *(const bf16x8*)((const bf16*)a.mask + (((long)n * H + hh) * W + ww) * CIN + ecc * 8);
+                } else {
+                    mk[half * EIT + it] = zero8();
+                    if (hh < H && ww < W) mk[half * EIT + it] = *(const bf16x8*)((const bf16*)a.mask + (((long)n * H + hh) * W + ww) * CIN + ecc * 8);
+                }
             }
     };
     if (has_mask && ntl > 0) mask_request(t0, mk_cur);
@@ -241,10 +257,10 @@ __global__ __launch_bounds__((NCW + 4) * 64, (NCW == 4 ? 4 : 3)) void conv3x3_ws
                 h = hh;
                 w = w0 + row;
                 m = ((long)n * H + h) * W + w;
-                return h < H && w < W;
+                return FULL ? true : (h < H && w < W);
             };
             const f32x4(&sub)[2][NT] = *reinterpret_cast<const f32x4(*)[2][NT]>(&acc[2 * half]);
-            if (half == 0 && has_mask && r + 1 < ntl) mask_request(t0 + r + 1, mk_nxt);
+            if (half == 0 && has_mask) mask_request(t0 + min(r + 1, ntl - 1), mk_nxt);      // (last tile: re-requests itself, unused)
             if (has_mask) conv_epilogue<BNB, NT>(a, sub, epi, 0, pix, s1, s2, bias_r, &mk_cur[half * EIT]);      // (two calls: a selected
             else conv_epilogue<BNB, NT>(a, sub, epi, 0, pix, s1, s2, bias_r, nullptr);                           //  pointer would pin the arrays in scratch)
         }
@@ -257,8 +273,8 @@ __global__ __launch_bounds__((NCW + 4) * 64, (NCW == 4 ? 4 : 3)) void conv3x3_ws
     if (a.stats != nullptr && ntl > 0) stats_flush<NT, NCW>(a, s1, s2, 0, red, epi_all, bid, event);
 }
 
-template <bool AFF, bool RELU, int RS, bool BNB, bool MPF>
-static int ws_launch_c(const ConvArgs& a, hipStream_t st) {
+template <bool AFF, bool RELU, int RS, bool BNB, bool MPF, bool FULL>
+static int ws_launch_f(const ConvArgs& a, hipStream_t st) {
     const int tiles_w = (a.W + WS_W - 1) / WS_W, tiles_h = (a.H + WS_H - 1) / WS_H;
     const int ntiles = a.N * tiles_w * tiles_h;
     const int n_events = (a.stats != nullptr && a.n_per_event > 0) ? a.N / a.n_per_event : 1;
@@ -276,7 +292,7 @@ static int ws_launch_c(const ConvArgs& a, hipStream_t st) {
         size_t tail = (size_t)NCWV * EpiLds<NTV>::FLOATS * 4;                                                                \
         if (tail < (size_t)NCWV * STATS_SX_FLOATS * 4) tail = (size_t)NCWV * STATS_SX_FLOATS * 4;                             \
         const size_t lds = (size_t)NTV * 16 * (KPV * 2 + 16) + 2 * (size_t)(WS_H + 2) * (WS_W + 2) * (CINV * 2 + 16) + tail;  \
-        auto kern = conv3x3_ws_kernel<AFF, RELU, RS, CINV, BNB, MPF, NCWV>;                                                  \
+        auto kern = conv3x3_ws_kernel<AFF, RELU, RS, CINV, BNB, MPF, NCWV, FULL>;                                            \
         static bool attr_set = false;                                                                                        \
         if (!attr_set) {                                                                                                     \
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
@@ -291,6 +307,12 @@ static int ws_launch_c(const ConvArgs& a, hipStream_t st) {
     WS_GO(16, 4)
 #undef WS_GO
     return 1;
+}
+
+template <bool AFF, bool RELU, int RS, bool BNB, bool MPF>
+static int ws_launch_c(const ConvArgs& a, hipStream_t st) {
+    if (a.H % WS_H == 0 && a.W % WS_W == 0) return ws_launch_f<AFF, RELU, RS, BNB, MPF, true>(a, st);
+    return ws_launch_f<AFF, RELU, RS, BNB, MPF, false>(a, st);
 }
 
 template <int RS>
