@@ -34,8 +34,14 @@ __device__ __forceinline__ int swz(int key, int chunk) {
     return (chunk & ~(G - 1)) | ((chunk ^ key) & (G - 1));
 }
 
-template <bool AFF, bool RELU, int RS, int CIN, int NT, int TH, int TW, int NW, bool BNB>
-__global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_lds_kernel(ConvArgs a, int tiles_w, int tiles_h, int tpe, int tpb, int nblk, int bpe) {
+// LDS image of one block (weight slice + halo): above 80 KB only ONE block fits a CU, whatever the register budget says
+template <int CIN, int NT, int TH, int TW>
+constexpr int lds_image_bytes() { return NT * 16 * 9 * CIN * 2 + (TH + 2) * (TW + 2) * CIN * 2; }
+
+// FULL: H % TH == 0 and W % TW == 0 -- every pixel of every tile exists, the epilogue's stores are unconditional and the compiler can
+// count them when the prefetched halo of the next tile is consumed (instead of draining the counter, stores included).
+template <bool AFF, bool RELU, int RS, int CIN, int NT, int TH, int TW, int NW, bool BNB, bool FULL = false>
+__global__ __launch_bounds__(NW * 64, (lds_image_bytes<CIN, NT, TH, TW>() > 80 * 1024 ? 1 : NW / 4)) void conv3x3_lds_kernel(ConvArgs a, int tiles_w, int tiles_h, int tpe, int tpb, int nblk, int bpe) {
     constexpr int AW = TW + 2, AH = TH + 2;
     constexpr int K = 9 * CIN;
     constexpr int KS = K / 32;
@@ -83,60 +89,118 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_lds_kernel(ConvArgs a
 #pragma unroll
     for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
     int aff_n = -1;
-    for (int t = t0; t < t1; ++t) {
-        const int n = t / (tiles_w * tiles_h);
+    // The raw halo of tile t+1 is requested into registers right before the K loop of tile t and written to LDS (prologue applied)
+    // after tile t's epilogue: with one block per CU (152 / 120 KB of LDS) nothing else hides a tile's load latency.  The requests
+    // are unconditional (coordinates clamped into the image, the padding ring zeroed through a mask; past the block's last tile
+    // the last tile is requested again and dropped) so that the compiler can count what is in flight behind them.
+    // (C = 128 only: the 8-wave C = 64 block sits at its 256-register cap and the extra live range spills -- 65 -> 70 us; C = 128
+    //  16x48 29.7 -> 27.2 us, 8x24 20.3 -> 16.8 us on one box)
+    constexpr bool XPF = CIN >= 128;
+    constexpr int HTOT = AH * AW * CH, HIT = XPF ? (HTOT + NTHR - 1) / NTHR : 1;
+    bf16x8 rawn[HIT];
+    unsigned okn = 0;
+    auto tile_of = [&](int t, int& n, int& h0, int& w0) {
+        n = t / (tiles_w * tiles_h);
         const int trem = t - n * tiles_w * tiles_h;
-        const int h0 = (trem / tiles_w) * TH, w0 = (trem % tiles_w) * TW;
+        h0 = (trem / tiles_w) * TH;
+        w0 = (trem % tiles_w) * TW;
+    };
+    auto request = [&](int t) {
+        int n, h0, w0;
+        tile_of(t, n, h0, w0);
+        okn = 0;
+#pragma unroll
+        for (int j = 0; j < HIT; ++j) {
+            const int idx = min((int)threadIdx.x + j * NTHR, HTOT - 1);
+            const int hp = idx / CH, cc = idx - hp * CH;
+            const int hh = h0 - 1 + hp / AW, ww = w0 - 1 + hp % AW;
+            const int hc = min(max(hh, 0), H - 1), wc = min(max(ww, 0), W - 1);
+            const int sh_ = (RS == 1) ? (hc >> 1) : hc, sw_ = (RS == 1) ? (wc >> 1) : wc;
+            rawn[j] = *(const bf16x8*)((const bf16*)a.src.x + (((long)n * a.src.Hs + sh_) * a.src.Ws + sw_) * a.src.Cx + cc * 8);
+            if ((int)threadIdx.x + j * NTHR < HTOT && hh >= 0 && hh < H && ww >= 0 && ww < W) okn |= 1u << j;
+        }
+    };
+    if constexpr (XPF) request(t0);
+    for (int t = t0; t < t1; ++t) {
+        int n, h0, w0;
+        tile_of(t, n, h0, w0);
         if (AFF && n != aff_n) {
             __syncthreads();
             stage_aff(aff_s, a.src, n, CIN);
             aff_n = n;
         }
         __syncthreads();              // previous tile's epilogue has left the halo region; the BatchNorm table is in place
-        // ---- halo -> LDS with the prologue applied: batches of SB independent loads per thread
-        {
-            constexpr int TOT = AH * AW * CH, ITERS = (TOT + NTHR - 1) / NTHR, SB = 10;
-#pragma unroll
-            for (int b0 = 0; b0 < ITERS; b0 += SB) {
-                bf16x8 rawb[SB];
-                unsigned okb = 0;
-#pragma unroll
-                for (int j = 0; j < SB; ++j) {
-                    const int idx = threadIdx.x + (b0 + j) * NTHR;
-                    if (b0 + j >= ITERS || idx >= TOT) continue;
-                    const int hp = idx / CH, cc = idx - hp * CH;
-                    const int hh = h0 - 1 + hp / AW, ww = w0 - 1 + hp % AW;
-                    if (hh >= 0 && hh < H && ww >= 0 && ww < W) {
-                        const int sh_ = (RS == 1) ? (hh >> 1) : hh, sw_ = (RS == 1) ? (ww >> 1) : ww;
-                        rawb[j] = *(const bf16x8*)((const bf16*)a.src.x + (((long)n * a.src.Hs + sh_) * a.src.Ws + sw_) * a.src.Cx + cc * 8);
-                        okb |= 1u << j;
+        if constexpr (XPF) {
+        // ---- halo -> LDS with the prologue applied
+    #pragma unroll
+            for (int j = 0; j < HIT; ++j) {
+                const int idx = threadIdx.x + j * NTHR;
+                if (idx >= HTOT) continue;
+                const int hp = idx / CH, cc = idx - hp * CH;
+                bf16x8 o = zero8();
+                if (okn & (1u << j)) {
+                    if (!AFF && RELU) {
+                        o = relu8(rawn[j]);
+                    } else if (AFF || RELU) {
+                        float v[8];
+    #pragma unroll
+                        for (int i = 0; i < 8; ++i) v[i] = bf2f(rawn[j][i]);
+                        xform8<AFF, RELU>(v, a.src, n, cc * 8, aff_s);
+    #pragma unroll
+                        for (int i = 0; i < 8; ++i) o[i] = f2bf(v[i]);
+                    } else {
+                        o = rawn[j];
                     }
                 }
-#pragma unroll
-                for (int j = 0; j < SB; ++j) {
-                    const int idx = threadIdx.x + (b0 + j) * NTHR;
-                    if (b0 + j >= ITERS || idx >= TOT) continue;
-                    const int hp = idx / CH, cc = idx - hp * CH;
-                    bf16x8 o = zero8();
-                    if (okb & (1u << j)) {
-                        if (!AFF && RELU) {
-                            o = relu8(rawb[j]);
-                        } else if (AFF || RELU) {
-                            float v[8];
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) v[i] = bf2f(rawb[j][i]);
-                            xform8<AFF, RELU>(v, a.src, n, cc * 8, aff_s);
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) o[i] = f2bf(v[i]);
-                        } else {
-                            o = rawb[j];
+                *(bf16x8*)(hsm + (hp * CH + swz<CH>(swz_key<CH>(hp % AW), cc)) * 16) = o;
+            }
+        } else {
+        // ---- halo -> LDS with the prologue applied: batches of SB independent loads per thread
+            {
+                constexpr int TOT = AH * AW * CH, ITERS = (TOT + NTHR - 1) / NTHR, SB = 10;
+    #pragma unroll
+                for (int b0 = 0; b0 < ITERS; b0 += SB) {
+                    bf16x8 rawb[SB];
+                    unsigned okb = 0;
+    #pragma unroll
+                    for (int j = 0; j < SB; ++j) {
+                        const int idx = threadIdx.x + (b0 + j) * NTHR;
+                        if (b0 + j >= ITERS || idx >= TOT) continue;
+                        const int hp = idx / CH, cc = idx - hp * CH;
+                        const int hh = h0 - 1 + hp / AW, ww = w0 - 1 + hp % AW;
+                        if (hh >= 0 && hh < H && ww >= 0 && ww < W) {
+                            const int sh_ = (RS == 1) ? (hh >> 1) : hh, sw_ = (RS == 1) ? (ww >> 1) : ww;
+                            rawb[j] = *(const bf16x8*)((const bf16*)a.src.x + (((long)n * a.src.Hs + sh_) * a.src.Ws + sw_) * a.src.Cx + cc * 8);
+                            okb |= 1u << j;
                         }
                     }
-                    *(bf16x8*)(hsm + (hp * CH + swz<CH>(swz_key<CH>(hp % AW), cc)) * 16) = o;
+    #pragma unroll
+                    for (int j = 0; j < SB; ++j) {
+                        const int idx = threadIdx.x + (b0 + j) * NTHR;
+                        if (b0 + j >= ITERS || idx >= TOT) continue;
+                        const int hp = idx / CH, cc = idx - hp * CH;
+                        bf16x8 o = zero8();
+                        if (okb & (1u << j)) {
+                            if (!AFF && RELU) {
+                                o = relu8(rawb[j]);
+                            } else if (AFF || RELU) {
+                                float v[8];
+    #pragma unroll
+                                for (int i = 0; i < 8; ++i) v[i] = bf2f(rawb[j][i]);
+                                xform8<AFF, RELU>(v, a.src, n, cc * 8, aff_s);
+    #pragma unroll
+                                for (int i = 0; i < 8; ++i) o[i] = f2bf(v[i]);
+                            } else {
+                                o = rawb[j];
+                            }
+                        }
+                        *(bf16x8*)(hsm + (hp * CH + swz<CH>(swz_key<CH>(hp % AW), cc)) * 16) = o;
+                    }
                 }
             }
         }
         __syncthreads();
+        if constexpr (XPF) request(min(t + 1, t1 - 1));  // in flight during the K loop and the epilogue below
         // ---- K loop from LDS: wave owns m-tiles [wave*MTW, +MTW) (tile row mt / MPR, columns (mt % MPR)*16 ..)
         f32x4 acc[MTW][NT];
 #pragma unroll
@@ -199,7 +263,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv3x3_lds_kernel(ConvArgs a
                 h = h0 + mtt / MPR;
                 w = w0 + (mtt % MPR) * 16 + (row & 15);
                 m = ((long)n * H + h) * W + w;
-                return h < H && w < W;
+                return FULL ? true : (h < H && w < W);
             };
             const f32x4(&sub)[2][NT] = *reinterpret_cast<const f32x4(*)[2][NT]>(&acc[2 * half]);
             conv_epilogue<BNB, NT, 2, false>(a, sub, epi, n_base, pix, s1, s2);
@@ -220,21 +284,25 @@ static int lds_launch(const ConvArgs& a, hipStream_t st) {
         const int ntiles = a.N * tiles_w * tiles_h;                                                                                \
         const int tpe = ntiles / n_events;                                                                                         \
         const int gy = (a.Cout + 16 * NTV - 1) / (16 * NTV);                                                                       \
-        /* one block per CU slot: a block reloads its weight slice only once, so let it walk several tiles on big maps */         \
-        int tpb = (ntiles * gy + 511) / 512;                                                                                       \
+        /* ONE round of persistent blocks (one or two per CU, by the LDS image): a block loads its weight slice once and keeps the \
+           next tile's halo in flight while it computes */                                                                         \
+        const int slots = (CINV) >= 128 ? 256 * (lds_image_bytes<CINV, NTV, THV, TWV>() > 80 * 1024 ? 1 : 2) : 512;                \
+        int tpb = (ntiles * gy + slots - 1) / slots;                                                                               \
         if (tpb < 1) tpb = 1;                                                                                                      \
         if (tpb > tpe) tpb = tpe;                                                                                                  \
         const int bpe = (tpe + tpb - 1) / tpb;                                                                                     \
         const int nblk = bpe * n_events;                                                                                           \
         const size_t lds = (size_t)NTV * 16 * 9 * CINV * 2 + (size_t)(THV + 2) * (TWV + 2) * CINV * 2;                             \
-        auto kern = conv3x3_lds_kernel<AFF, RELU, RS, CINV, NTV, THV, TWV, NWV, BNB>;                                              \
-        static bool attr_set = false;                                                                                              \
-        if (!attr_set) {                                                                                                           \
+        const bool full = a.H % THV == 0 && a.W % TWV == 0;                                                                        \
+        auto kern = full ? conv3x3_lds_kernel<AFF, RELU, RS, CINV, NTV, THV, TWV, NWV, BNB, true>                                  \
+                         : conv3x3_lds_kernel<AFF, RELU, RS, CINV, NTV, THV, TWV, NWV, BNB, false>;                                \
+        static bool attr_set[2] = {false, false};                                                                                  \
+        if (!attr_set[full]) {                                                                                                     \
             if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {      \
                 ieagan_set_error("conv3x3_lds: cannot reserve %zu bytes of LDS", lds);                                             \
                 return IEAGAN_ELAUNCH;                                                                                             \
             }                                                                                                                      \
-            attr_set = true;                                                                                                       \
+            attr_set[full] = true;                                                                                                 \
         }                                                                                                                          \
         hipLaunchKernelGGL(kern, dim3(nblk, gy), dim3(NWV * 64), lds, st, a, tiles_w, tiles_h, tpe, tpb, nblk, bpe);               \
         return 1;                                                                                                                  \
