@@ -94,6 +94,16 @@ def physical_cores():
         return None
 
 
+def leave():
+    """Exit without interpreter teardown once the record is printed -- unless a profiler is attached (rocprofv3 writes its
+    files from exit handlers)."""
+    sys.stdout.flush()
+    sys.stderr.flush()
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return
+    os._exit(0)
+
+
 def cpu_baseline(cfg, mode="sub", threads=None):
     """The oracle's train step at full 256x768 resolution on this host's cores.  ``full``: all 40 sensors, 1 warm-up + 1
     timed step (minutes of CPU time and ~30 GB of host memory).  ``sub`` (default, bounded to tens of
@@ -405,9 +415,7 @@ def main():
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
-        sys.stdout.flush()
-        sys.stderr.flush()
-        os._exit(0)               # (as rank 0 below: no interpreter teardown after the measurement)
+        leave()                   # (as rank 0 below: no interpreter teardown after the measurement)
     E, h, w, dt, steps = m["E"], m["h"], m["w"], m["dt"], m["steps"]
     desc1 = (f"BASELINE configs[1]: 1 event (40x1x{h}x{w}) per GPU per step, hinge loss only, RRM on, DiffAugment on, ortho reg + "
              "Adam + EMA in the timed region, fp32 master weights, 4 synthetic events in rotation")
@@ -452,9 +460,7 @@ def main():
     # The record is out: leave without interpreter teardown.  (One run of the default command died with SIGSEGV AFTER printing
     # its complete record, somewhere in the destruction order of HIP graphs / streams / the CPU baseline's worker threads at
     # exit; a benchmark's exit status should not depend on that.)
-    sys.stdout.flush()
-    sys.stderr.flush()
-    os._exit(0)
+    leave()
 
 
 if __name__ == "__main__":
