@@ -12,7 +12,7 @@ from collections import defaultdict
 
 def family(name):
     n = re.sub(r"^void ", "", name)
-    if n.startswith("conv_gather_kernel<1") or n.startswith("conv1x1_stream_kernel"): return "conv1x1_gather"      # (bench.py family names)
+    if n.startswith("conv_gather_kernel<1") or n.startswith("conv1x1_stream_kernel") or n.startswith("conv1x1_tile_kernel"): return "conv1x1_gather"      # (bench.py family names)
     if n.startswith("conv3x3_lds_kernel") or n.startswith("conv3x3_lds_fp8_kernel") or n.startswith("conv3x3_ws_kernel"): return "conv3x3_halo"
     if n.startswith("conv1x1_bwd_kernel"): return "conv1x1_bwd"
     if n.startswith("d_stem_fwd_kernel"): return "d_stem_fwd"
