@@ -62,7 +62,7 @@ class ProfRec(C.Structure):
                 ("flops", C.c_double), ("bytes", C.c_double), ("bytes_min", C.c_double)]
 
 
-ABI_VERSION = 7            # include/ieagan_hip.h: IEAGAN_ABI_VERSION
+ABI_VERSION = 8            # include/ieagan_hip.h: IEAGAN_ABI_VERSION
 i, f, l = C.c_int, C.c_float, C.c_long
 _SIGS = {
     "ieagan_abi_version": [],
@@ -103,6 +103,7 @@ _SIGS = {
     "ieagan_embed_norm_fwd": [vp, vp, vp, vp, i, i, vp],
     "ieagan_embed_norm_bwd": [vp, vp, vp, vp, vp, i, i, vp],
     "ieagan_loss_block": [vp, vp, vp, vp, vp, C.POINTER(C.c_float), f, vp, vp, vp, vp, vp, i, i, vp],
+    "ieagan_loss_block_events": [vp, vp, vp, vp, vp, C.POINTER(C.c_float), f, vp, vp, vp, vp, vp, i, i, i, vp],
     "ieagan_relu_sum_pool": [vp, vp, i, i, i, vp],
     "ieagan_relu_sum_pool_bwd": [vp, vp, vp, i, i, i, vp],
     "ieagan_diffaug_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, vp],

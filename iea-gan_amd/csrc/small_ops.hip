@@ -205,6 +205,20 @@ __device__ void gram(const float* __restrict__ A, const float* __restrict__ B, f
 }
 
 __global__ __launch_bounds__(1024) void loss_block_kernel(LossArgs a) {
+    // one block per event: the batch holds gridDim.x events of n rows each (the Grams are intra-event)
+    {
+        const long ev = blockIdx.x;
+        if (a.dfake) a.dfake += ev * a.n;
+        if (a.dreal) a.dreal += ev * a.n;
+        if (a.e) a.e += ev * a.n * a.d;
+        if (a.p) a.p += ev * a.n * a.d;
+        if (a.er) a.er += ev * a.n * a.d;
+        if (a.g_dfake) a.g_dfake += ev * a.n;
+        if (a.g_dreal) a.g_dreal += ev * a.n;
+        if (a.g_e) a.g_e += ev * a.n * a.d;
+        if (a.g_p) a.g_p += ev * a.n * a.d;
+        a.vals += ev * 8;
+    }
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ float red[16];
     __shared__ float sc[8];
@@ -389,10 +403,21 @@ __global__ __launch_bounds__(1024) void loss_block_kernel(LossArgs a) {
     (void)rowa; (void)rowb;
 }
 
+extern "C" int ieagan_loss_block_events(const float* dfake, const float* dreal, const float* e, const float* p, const float* er,
+                                        const float* weights6, float temperature, float* vals8, float* g_dfake, float* g_dreal, float* g_e,
+                                        float* g_p, int n, int d, int events, void* stream);
+
 extern "C" int ieagan_loss_block(const float* dfake, const float* dreal, const float* e, const float* p, const float* er,
                                  const float* weights6, float temperature, float* vals8, float* g_dfake, float* g_dreal, float* g_e,
                                  float* g_p, int n, int d, void* stream) {
+    return ieagan_loss_block_events(dfake, dreal, e, p, er, weights6, temperature, vals8, g_dfake, g_dreal, g_e, g_p, n, d, 1, stream);
+}
+
+extern "C" int ieagan_loss_block_events(const float* dfake, const float* dreal, const float* e, const float* p, const float* er,
+                                        const float* weights6, float temperature, float* vals8, float* g_dfake, float* g_dreal, float* g_e,
+                                        float* g_p, int n, int d, int events, void* stream) {
     CHECK_ARG(n >= 2 && n <= SMAX, "loss_block: n must be in [2, %d]", SMAX);
+    CHECK_ARG(events >= 1, "loss_block: events must be >= 1 (got %d)", events);
     LossArgs a;
     a.dfake = dfake; a.dreal = dreal; a.e = e; a.p = p; a.er = er;
     for (int i = 0; i < 6; ++i) a.w[i] = weights6[i];
@@ -402,7 +427,7 @@ extern "C" int ieagan_loss_block(const float* dfake, const float* dreal, const f
     const size_t lds = (size_t)(3 * n * n + 2 * n * 65 + 6 * n) * 4;
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof("loss_block", 0.0, 0.0, st);
-    hipLaunchKernelGGL(loss_block_kernel, dim3(1), dim3(1024), lds, st, a);
+    hipLaunchKernelGGL(loss_block_kernel, dim3(events), dim3(1024), lds, st, a);
     CHECK_LAUNCH("loss_block");
     return 0;
 }

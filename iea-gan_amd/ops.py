@@ -1397,38 +1397,44 @@ class LossBlockFn(torch.autograd.Function):
     Returns (total, terms[8]); only ``total`` is differentiable."""
 
     @staticmethod
-    def forward(ctx, dfake, dreal, e, p, er, weights, temperature):
+    def forward(ctx, dfake, dreal, e, p, er, weights, temperature, events=1):
         import ctypes
         ref = next(t for t in (dfake, dreal, e) if t is not None)
         dev = ref.device
-        n = ref.shape[0]
+        if ref.shape[0] % events != 0:
+            raise ValueError(f"loss_block: {ref.shape[0]} rows are not {events} whole events")
+        n = ref.shape[0] // events
         d = e.shape[1] if e is not None else 0
         c = lambda t: None if t is None else t.contiguous().float()
         dfake, dreal, e, p, er = c(dfake), c(dreal), c(e), c(p), c(er)
-        vals = torch.empty(8, dtype=torch.float32, device=dev)
+        vals = torch.empty(events, 8, dtype=torch.float32, device=dev)
         g_df = torch.empty_like(dfake) if dfake is not None else None
         g_dr = torch.empty_like(dreal) if dreal is not None else None
         g_e = torch.empty_like(e) if e is not None else None
         g_p = torch.empty_like(p) if p is not None else None
         w = (ctypes.c_float * 6)(*[float(x) for x in weights])
-        H.call("ieagan_loss_block", H.ptr(dfake), H.ptr(dreal), H.ptr(e), H.ptr(p), H.ptr(er), w, float(temperature),
-               vals.data_ptr(), H.ptr(g_df), H.ptr(g_dr), H.ptr(g_e), H.ptr(g_p), n, d, H.stream())
+        # one workgroup per event (the Grams / hinge means are intra-event); total = mean over the events
+        H.call("ieagan_loss_block_events", H.ptr(dfake), H.ptr(dreal), H.ptr(e), H.ptr(p), H.ptr(er), w, float(temperature),
+               vals.data_ptr(), H.ptr(g_df), H.ptr(g_dr), H.ptr(g_e), H.ptr(g_p), n, d, int(events), H.stream())
         ctx.save_for_backward(g_df, g_dr, g_e, g_p)
-        terms = vals.clone()
+        ctx.events = int(events)
+        terms = vals.mean(0) if events > 1 else vals[0].clone()
         ctx.mark_non_differentiable(terms)
-        return vals[0], terms
+        return (vals[:, 0].mean() if events > 1 else vals[0, 0]), terms
 
     @staticmethod
     def backward(ctx, gtotal, _gterms):
         g_df, g_dr, g_e, g_p = ctx.saved_tensors
-        m = lambda t: None if t is None else t * gtotal
-        return m(g_df), m(g_dr), m(g_e), m(g_p), None, None, None
+        sc = gtotal / float(ctx.events)
+        m = lambda t: None if t is None else t * sc
+        return m(g_df), m(g_dr), m(g_e), m(g_p), None, None, None, None
 
 
 def loss_block(dfake=None, dreal=None, e=None, p=None, er=None, w_hinge_real=0.0, w_hinge_fake=0.0, w_hinge_gen=0.0,
-               w_contra=0.0, w_unif=0.0, w_iea=0.0, temperature=1.0):
-    """(total, terms) with terms = [total, hinge_real, hinge_fake, hinge_gen, contrastive, uniformity, iea, 0]."""
-    return LossBlockFn.apply(dfake, dreal, e, p, er, (w_hinge_real, w_hinge_fake, w_hinge_gen, w_contra, w_unif, w_iea), temperature)
+               w_contra=0.0, w_unif=0.0, w_iea=0.0, temperature=1.0, events=1):
+    """(total, terms) with terms = [total, hinge_real, hinge_fake, hinge_gen, contrastive, uniformity, iea, 0].  ``events`` > 1: the
+    tensors hold that many events of equal size; every term is evaluated per event (one workgroup each, one launch) and averaged."""
+    return LossBlockFn.apply(dfake, dreal, e, p, er, (w_hinge_real, w_hinge_fake, w_hinge_gen, w_contra, w_unif, w_iea), temperature, events)
 
 
 class ReluSumPoolFn(torch.autograd.Function):

@@ -146,17 +146,8 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
 
     def per_event(**kw):
         """The fused loss block evaluated per event (the contrastive / uniformity / IEA Grams are intra-event) and averaged:
-        (total, terms).  One launch per event; E = 1 is the plain call."""
-        if E == 1:
-            return ops.loss_block(**kw)
-        tensors = {k: v for k, v in kw.items() if torch.is_tensor(v)}
-        rest = {k: v for k, v in kw.items() if not torch.is_tensor(v)}
-        total = terms = None
-        for e in range(E):
-            tt, tm = ops.loss_block(**{k: v[e * bs:(e + 1) * bs] for k, v in tensors.items()}, **rest)
-            total = tt if total is None else total + tt
-            terms = tm if terms is None else terms + tm
-        return total / float(E), terms / float(E)
+        (total, terms).  One launch, one workgroup per event."""
+        return ops.loss_block(**kw, events=E)
 
     # Spectral-norm passes ahead of time on a side stream (ops.SNBank.prefetch): 4 of the 5 passes of a step depend on weights
     # that are final long before the forward that consumes them.  Single-GPU default step only (split_D, no accumulation): the

@@ -19,7 +19,7 @@ extern "C" {
 #endif
 
 const char* ieagan_last_error(void);
-#define IEAGAN_ABI_VERSION 7        /* bumped whenever a struct layout or a signature in this header changes */
+#define IEAGAN_ABI_VERSION 8        /* bumped whenever a struct layout or a signature in this header changes */
 int ieagan_abi_version(void);        /* == IEAGAN_ABI_VERSION of the header the library was built from */
 
 /* ---- profiling hooks (bench.py): per-kernel HIP-event timing on the launch stream ---- */
@@ -280,6 +280,11 @@ int ieagan_embed_norm_bwd(const long* y, const float* p, const float* inv, const
 int ieagan_loss_block(const float* dfake, const float* dreal, const float* e, const float* p, const float* er,
                       const float* weights6, float temperature, float* vals8, float* g_dfake, float* g_dreal, float* g_e,
                       float* g_p, int n, int d, void* stream);
+/* the same for a batch of `events` events of n rows each (one workgroup per event; all tensors hold events * n rows, vals8 is
+ * [events][8], the gradients are those of each event's own total) */
+int ieagan_loss_block_events(const float* dfake, const float* dreal, const float* e, const float* p, const float* er,
+                      const float* weights6, float temperature, float* vals8, float* g_dfake, float* g_dreal, float* g_e,
+                      float* g_p, int n, int d, int events, void* stream);
 /* D head: global sum pool of relu(h) (model.py:912) */
 int ieagan_relu_sum_pool(const void* x, float* out, int N, int HW, int C, void* stream);
 int ieagan_relu_sum_pool_bwd(const void* x, const float* dh, void* dx, int N, int HW, int C, void* stream);
