@@ -149,13 +149,42 @@ __global__ __launch_bounds__(256, 3) void d_stem_fwd_kernel(DStemArgs a, int til
     const int ntiles = a.N * tiles_w * tiles_h;
     const int per = (ntiles + gridDim.x - 1) / gridDim.x;
     const int tile_end = min((int)(blockIdx.x + 1) * per, ntiles);
-    for (int tile = blockIdx.x * per; tile < tile_end; ++tile) {
+    // The image halo of tile t+1 (340 floats) is requested into two registers per thread right after tile t's halo went to LDS, and
+    // every global access of the loop is unconditional (coordinates clamped, the padding ring zeroed through a mask; all 64 lanes
+    // store): this kernel writes 0.5 GB per launch, and a halo load that follows the stores in program order -- or that the
+    // compiler cannot count past -- waits for every one of them (stores count on vmcnt on gfx9).
+    constexpr int AWH = ST_TW + 2, AHH = ST_TH + 2, HN = (AHH * AWH + 255) / 256;
+    float hn[HN];
+    unsigned hok = 0;
+    auto request = [&](int tile) {
+        const int n = tile / (tiles_w * tiles_h);
+        const int trem = tile - n * tiles_w * tiles_h;
+        const int y0 = (trem / tiles_w) * ST_TH, x0 = (trem % tiles_w) * ST_TW;
+        const float* im = a.img + (long)n * H * W;
+        hok = 0;
+#pragma unroll
+        for (int j = 0; j < HN; ++j) {
+            const int i = min((int)threadIdx.x + j * 256, AHH * AWH - 1);
+            const int qy = i / AWH, qx = i - qy * AWH;
+            const int yy = y0 - 1 + qy, xx = x0 - 1 + qx;
+            hn[j] = im[(long)min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)];
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) hok |= 1u << j;
+        }
+    };
+    const int tile_begin = blockIdx.x * per;
+    if (tile_begin < tile_end) request(tile_begin);
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
         const int n = tile / (tiles_w * tiles_h);
         const int trem = tile - n * tiles_w * tiles_h;
         const int y0 = (trem / tiles_w) * ST_TH, x0 = (trem % tiles_w) * ST_TW;
         __syncthreads();
-        st_load_halo(halo, a.img + (long)n * H * W, H, W, y0, x0);
+#pragma unroll
+        for (int j = 0; j < HN; ++j) {
+            const int i = threadIdx.x + j * 256;
+            if (i < AHH * AWH) halo[i / AWH][i % AWH] = (hok & (1u << j)) ? hn[j] : 0.f;
+        }
         __syncthreads();
+        request(min(tile + 1, tile_end - 1));                      // (last tile: re-requests itself, unused)
         st_h0_tile(halo, wave, lane, bin, bv, o, h0s);
         // ---- conv1: h1[px][16] = h0[px][32] W1^T + b1, one K step; 16 pixels per MFMA
 #pragma unroll
@@ -166,8 +195,8 @@ __global__ __launch_bounds__(256, 3) void d_stem_fwd_kernel(DStemArgs a, int til
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[(4 * lg + r) * ST_LDO + lr] = d[r];
             ST_WAVE_FENCE();
-            if (lane < 32) {                                       // 16 pixels x 2 chunks
-                const int px = lane >> 1, cc = lane & 1;
+            {                                                      // 16 pixels x 2 chunks: lanes 32..63 repeat lanes 0..31 (the same
+                const int px = (lane & 31) >> 1, cc = lane & 1;    // bytes to the same address: an unconditional store instruction)
                 const f32x4 lo = *(const f32x4*)(o + px * ST_LDO + cc * 8);
                 const f32x4 hi = *(const f32x4*)(o + px * ST_LDO + cc * 8 + 4);
                 bf16x8 ov;
@@ -253,12 +282,17 @@ __global__ __launch_bounds__(256, 2) void d_stem_bwd_kernel(DStemArgs a, int til
     const int ntiles = a.N * tiles_w * tiles_h;
     const int per = (ntiles + gridDim.x - 1) / gridDim.x;
     const int tile_end = min((int)(blockIdx.x + 1) * per, ntiles);
-    for (int tile = blockIdx.x * per; tile < tile_end; ++tile) {
+    // Every operand of tile t+1 -- dh1 (64 pixels x 2 chunks per wave), dp0 (16 pooled pixels x 4 chunks), the image halo -- is
+    // requested into registers (unconditionally, halo coordinates clamped) once tile t's copies sit in LDS: the 60 tiles of a block
+    // were a chain of exposed load latencies.
+    constexpr int AWH = ST_TW + 2, AHH = ST_TH + 2, HN = (AHH * AWH + 255) / 256;
+    bf16x8 rg[2], rp;
+    float hn[HN];
+    unsigned hok = 0;
+    auto request = [&](int tile) {
         const int n = tile / (tiles_w * tiles_h);
         const int trem = tile - n * tiles_w * tiles_h;
         const int y0 = (trem / tiles_w) * ST_TH, x0 = (trem % tiles_w) * ST_TW;
-        // requests of this wave's operands first: dh1 (64 pixels x 2 chunks), dp0 (16 pooled pixels x 4 chunks)
-        bf16x8 rg[2], rp;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int item = j * 64 + lane, p = item >> 1, cc = item & 1;
@@ -269,16 +303,39 @@ __global__ __launch_bounds__(256, 2) void d_stem_bwd_kernel(DStemArgs a, int til
             const int ppx = lane >> 2;
             rp = *(const bf16x8*)((const bf16*)a.dp0 + (((long)n * Hp + (y0 >> 1) + wave) * Wp + (x0 >> 1) + ppx) * ST_C0 + cc4 * 8);
         }
-        __syncthreads();
-        st_load_halo(halo, a.img + (long)n * H * W, H, W, y0, x0);
-        __syncthreads();
-        st_h0_tile(halo, wave, lane, bin, bv, o, h0s);
+        const float* im = a.img + (long)n * H * W;
+        hok = 0;
+#pragma unroll
+        for (int j = 0; j < HN; ++j) {
+            const int i = min((int)threadIdx.x + j * 256, AHH * AWH - 1);
+            const int qy = i / AWH, qx = i - qy * AWH;
+            const int yy = y0 - 1 + qy, xx = x0 - 1 + qx;
+            hn[j] = im[(long)min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)];
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) hok |= 1u << j;
+        }
+    };
+    const int tile_begin = blockIdx.x * per;
+    if (tile_begin < tile_end) request(tile_begin);
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        const int n = tile / (tiles_w * tiles_h);
+        const int trem = tile - n * tiles_w * tiles_h;
+        const int y0 = (trem / tiles_w) * ST_TH, x0 = (trem % tiles_w) * ST_TW;
+        (void)n;
+        __syncthreads();                                           // the previous tile is done with halo / g1s / dps
+#pragma unroll
+        for (int j = 0; j < HN; ++j) {
+            const int i = threadIdx.x + j * 256;
+            if (i < AHH * AWH) halo[i / AWH][i % AWH] = (hok & (1u << j)) ? hn[j] : 0.f;
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int item = j * 64 + lane, p = item >> 1, cc = item & 1;
             *(bf16x8*)(g1s + p * ST_C1 + cc * 8) = rg[j];
         }
         *(bf16x8*)(dps + (lane >> 2) * ST_XS + cc4 * 8) = rp;
+        __syncthreads();
+        request(min(tile + 1, tile_end - 1));                      // (last tile: re-requests itself, unused)
+        st_h0_tile(halo, wave, lane, bin, bv, o, h0s);
         ST_WAVE_FENCE();
         // ---- dh0 = dh1 W1 + 0.25 expand(dp0), rounded to bf16 (what the separate path stored), LDS only
 #pragma unroll
