@@ -178,7 +178,22 @@ __global__ __launch_bounds__(256) void conv_Cto1_kernel(const bf16* __restrict__
                 sh[ks][j] = (c < C) ? shift[(long)n * nstride + c] : 0.f;
             }
     }
-    for (int mt = wave; mt < MTILES; mt += 4) {
+    // all of a wave's halo fragments (11 m-tiles) are requested before the first one is used: unconditional loads (coordinates and
+    // channel group clamped, zeroed below) -- one tile per block, so nothing else overlaps a wave's load latencies
+    constexpr int MPW = (MTILES + 3) / 4;
+    bf16x8 raw[MPW][KS];
+#pragma unroll
+    for (int i = 0; i < MPW; ++i) {
+        const int q = min((wave + 4 * i) * 16 + lr, NPIX - 1);
+        const int qy = q / AW, qx = q - qy * AW;
+        const int yc = min(max(y0 - 1 + qy, 0), H - 1), xc = min(max(x0 - 1 + qx, 0), W - 1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) raw[i][ks] = *(const bf16x8*)(x + (((long)n * H + yc) * W + xc) * C + min(ks * 32 + lg * 8, C - 8));
+    }
+#pragma unroll
+    for (int i = 0; i < MPW; ++i) {
+        const int mt = wave + 4 * i;
+        if (mt >= MTILES) break;
         const int q = mt * 16 + lr;
         const int qy = q / AW, qx = q - qy * AW;
         const int yy = y0 - 1 + qy, xx = x0 - 1 + qx;
@@ -189,7 +204,7 @@ __global__ __launch_bounds__(256) void conv_Cto1_kernel(const bf16* __restrict__
             const int c0 = ks * 32 + lg * 8;
             bf16x8 af = zero8();
             if (ok && c0 < C) {
-                af = *(const bf16x8*)(x + (((long)n * H + yy) * W + xx) * C + c0);
+                af = raw[i][ks];
                 if (AFF || RELU) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
