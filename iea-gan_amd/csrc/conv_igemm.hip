@@ -208,9 +208,7 @@ static int launch_gather_pro(const ConvArgs& a, hipStream_t st) {
 #define HT_H 8
 #define HT_W 32
 
-// FULL (prefetching variants): no partial tiles -- the epilogue's stores are unconditional, so the compiler can count them when the
-// next tile's prefetched halo is consumed instead of draining the counter (on gfx9 stores count on vmcnt like loads).
-template <bool AFF, bool RELU, int RS, int NT, int PF, int CIN, bool BNB = false, bool FULL = false>
+template <bool AFF, bool RELU, int RS, int NT, int PF, int CIN, bool BNB = false>
 __global__ __launch_bounds__(256, ((CIN >= 64 && PF == 0) ? 2 : (CIN == 16 ? 4 : (CIN == 32 ? 3 : 1)))) void conv3x3_halo_kernel(ConvArgs a, int tiles_w, int tiles_h, int tpe, int tpb, int nblk, int bpe) {
     extern __shared__ __attribute__((aligned(16))) char smem_all[];
     __shared__ float red[4 * NT * 16 * 2];
@@ -265,18 +263,6 @@ __global__ __launch_bounds__(256, ((CIN >= 64 && PF == 0) ? 2 : (CIN == 16 ? 4 :
         okmask = 0;
 #pragma unroll
         for (int j = 0; j < PF; ++j) {
-            if (FULL) {
-                // unconditional requests (coordinates clamped into the image; the padding ring is zeroed through okmask in
-                // store_tile): under a per-lane condition the compiler cannot count what is in flight behind them
-                const int idx = min((int)threadIdx.x + j * 256, total - 1);
-                const int hp = idx / chunks, cc = idx - hp * chunks;
-                const int hh = h0 - 1 + hp / AW, ww = w0 - 1 + hp % AW;
-                const int hc = min(max(hh, 0), H - 1), wc = min(max(ww, 0), W - 1);
-                const int sh_ = (RS == 1) ? (hc >> 1) : hc, sw_ = (RS == 1) ? (wc >> 1) : wc;
-                raw[j] = *(const bf16x8*)((const bf16*)a.src.x + (((long)n * a.src.Hs + sh_) * a.src.Ws + sw_) * a.src.Cx + cc * 8);
-                if ((int)threadIdx.x + j * 256 < total && hh >= 0 && hh < H && ww >= 0 && ww < W) okmask |= 1u << j;
-                continue;
-            }
             const int idx = threadIdx.x + j * 256;
             const int hp = idx / chunks, cc = idx - hp * chunks;
             const int hh = h0 - 1 + hp / AW, ww = w0 - 1 + hp % AW;
@@ -389,10 +375,7 @@ __global__ __launch_bounds__(256, ((CIN >= 64 && PF == 0) ? 2 : (CIN == 16 ? 4 :
             }
         }
         __syncthreads();
-        if (PF > 0) {                                       // in flight during the MFMA loop below
-            if (FULL) load_tile(min(t + 1, t1 - 1));        // (last tile: re-requests itself, unused -- the request count stays fixed)
-            else if (t + 1 < t1) load_tile(t + 1);
-        }
+        if (PF > 0 && t + 1 < t1) load_tile(t + 1);       // in flight during the MFMA loop below
 
         f32x4 acc[4][NT];
 #pragma unroll
@@ -480,7 +463,7 @@ __global__ __launch_bounds__(256, ((CIN >= 64 && PF == 0) ? 2 : (CIN == 16 ? 4 :
                 h = hh;
                 w = w0 + row;
                 m = ((long)n * H + h) * W + w;
-                return FULL ? true : (h < H && w < W);
+                return h < H && w < W;
             };
             const f32x4(&sub)[2][NT] = *reinterpret_cast<const f32x4(*)[2][NT]>(&acc[2 * half]);
             conv_epilogue<BNB, NT, 2, false>(a, sub, epi, n_base, pix, s1, s2);
@@ -511,17 +494,10 @@ static int launch_halo_nt(const ConvArgs& a, hipStream_t st) {
         int tp = (PFV) > 0 ? tpb : 1;                                                                        \
         if ((PFV) > 0 && (CINV) >= 64) { tp = (ntiles + 255) / 256; if (tp > 8) tp = 8; }   /* one persistent block per CU */ \
         if ((PFV) > 0) lds += (size_t)NTV * 16 * (a.Kpad * 2 + 16);                                          \
-        /* (dgrad launches with a ReLU-mask / BatchNorm-backward epilogue only: 121 -> 111 us at 128x384; the forward variants measured 2-4 % slower) */ \
-        const bool full = (PFV) > 0 && (CINV) == 32 && a.H % HT_H == 0 && a.W % HT_W == 0 && ntiles >= 3072 && a.mask != nullptr; \
-        if (full) { tp = (ntiles + 767) / 768; if (tp > tpe) tp = tpe; }   /* one round of persistent blocks, three per CU */ \
         const int bpe = (tpe + tp - 1) / tp;                                                                 \
         const int nblk = bpe * n_events;                                                                     \
-        if (full)                                                                                            \
-            hipLaunchKernelGGL((conv3x3_halo_kernel<AFF, RELU, RS, NTV, PFV, CINV, BNB, ((PFV) > 0 && (CINV) == 32)>), dim3(nblk, (a.Cout + 16 * NTV - 1) / (16 * NTV)), \
-                               dim3(256), lds, st, a, tiles_w, tiles_h, tpe, tp, nblk, bpe);                 \
-        else                                                                                                 \
-            hipLaunchKernelGGL((conv3x3_halo_kernel<AFF, RELU, RS, NTV, PFV, CINV, BNB>), dim3(nblk, (a.Cout + 16 * NTV - 1) / (16 * NTV)), \
-                               dim3(256), lds, st, a, tiles_w, tiles_h, tpe, tp, nblk, bpe);                 \
+        hipLaunchKernelGGL((conv3x3_halo_kernel<AFF, RELU, RS, NTV, PFV, CINV, BNB>), dim3(nblk, (a.Cout + 16 * NTV - 1) / (16 * NTV)), \
+                           dim3(256), lds, st, a, tiles_w, tiles_h, tpe, tp, nblk, bpe);                     \
     }
     // prefetching variants: Cin = Cout = 16 / 32 (PF = ceil(340 * Cin/8 / 256) = 3 / 6)
     // small feature maps: fewer channels per block so that the grid still covers the 256 CUs
