@@ -62,7 +62,7 @@ class ProfRec(C.Structure):
                 ("flops", C.c_double), ("bytes", C.c_double), ("bytes_min", C.c_double)]
 
 
-ABI_VERSION = 8            # include/ieagan_hip.h: IEAGAN_ABI_VERSION
+ABI_VERSION = 9            # include/ieagan_hip.h: IEAGAN_ABI_VERSION
 i, f, l = C.c_int, C.c_float, C.c_long
 _SIGS = {
     "ieagan_abi_version": [],
@@ -86,6 +86,7 @@ _SIGS = {
     "ieagan_nhwc_to_nchw": [vp, vp, i, i, i, vp],
     "ieagan_channel_stats": [vp, vp, l, i, vp],
     "ieagan_conv_1toC": [vp, vp, vp, vp, vp, i, i, i, i, i, vp],
+    "ieagan_conv_1toC_bnb": [vp, vp, vp, vp, vp, vp, i, i, vp, vp, vp, i, i, i, i, i, vp],
     "ieagan_conv_Cto1": [vp, vp, vp, i, i, vp, vp, vp, i, i, i, i, i, i, vp],
     "ieagan_wgrad_c1": [vp, vp, vp, vp, vp, i, i, vp, i, i, i, i, i, vp],
     "ieagan_sn_backward_batched": [vp, vp, i, vp, vp, vp, vp, vp],

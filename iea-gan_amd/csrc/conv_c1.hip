@@ -16,11 +16,22 @@
 // w: fp32 [9][C].  tanh_y (optional): the image is multiplied by (1 - y*y) first (tanh backward).
 #define I1_TH 8
 #define I1_TW 32
-template <int C>
+// BNB (the dgrad of G.output_layer): the BatchNorm-apply + ReLU backward of the layer's prologue is done in the store phase -- the
+// value stored is d * scale[c] with d = ReLU'(x * scale + shift) * conv, and sum d / sum d * x go to dshift / dscale (row n * nstride) --
+// so the [N, H, W, C] gradient w.r.t. the activated tensor (0.5 GB at 256x768) is never written or read back.
+struct C1Bnb {
+    const bf16* x;            // the BatchNorm input, bf16 [N, H, W, C]
+    const float* scale;       // rows n * nstride
+    const float* shift;
+    int nstride, relu;
+    float* dscale;            // accumulated (atomics), rows n * nstride
+    float* dshift;
+};
+template <int C, bool BNB = false>
 __global__ __launch_bounds__(256) void conv_1toC_kernel(const float* __restrict__ img, const float* __restrict__ tanh_y,
                                                         const float* __restrict__ w, const float* __restrict__ bias,
                                                         bf16* __restrict__ out, int N, int H, int W, int flip, int tiles_w,
-                                                        int tiles_h) {
+                                                        int tiles_h, C1Bnb bnb = C1Bnb{}) {
     constexpr int NT = C / 16;
     constexpr int AW = I1_TW + 2, AH = I1_TH + 2;
     constexpr int LDO = C + 4;                                   // padded fp32 row of the transposed output tile
@@ -47,8 +58,42 @@ __global__ __launch_bounds__(256) void conv_1toC_kernel(const float* __restrict_
     const int ntiles = N * tiles_w * tiles_h;
     const int per = (ntiles + gridDim.x - 1) / gridDim.x;
     const int tile_end = min((int)(blockIdx.x + 1) * per, ntiles);
+    constexpr int SIT = (16 * (C / 8) + 63) / 64;                // store-phase items per lane and m-tile
+    __shared__ float bred[BNB ? 256 * 8 : 8];
+    float bsc[8], bsh[8], p_ds[8], p_dt[8];
+    int bn_n = -1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bsc[i] = bsh[i] = p_ds[i] = p_dt[i] = 0.f;
+    // sum over the lanes of the block that own channel chunk cc, one atomic per channel (cf. bn_elem.hip reduce_groups_atomic)
+    auto bnb_flush = [&](int n_row) {
+        constexpr int G = C / 8;
+#pragma unroll
+        for (int w2 = 0; w2 < 2; ++w2) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) bred[threadIdx.x * 8 + i] = w2 ? p_dt[i] : p_ds[i];
+            __syncthreads();
+            for (int o2 = threadIdx.x; o2 < C; o2 += 256) {
+                const int g = o2 >> 3, i = o2 & 7;
+                float sacc = 0.f;
+                for (int u = g; u < 256; u += G) sacc += bred[u * 8 + i];
+                atomicAdd((w2 ? bnb.dshift : bnb.dscale) + (long)n_row * bnb.nstride + o2, sacc);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p_ds[i] = p_dt[i] = 0.f;
+    };
     for (int tile = blockIdx.x * per; tile < tile_end; ++tile) {
     const int n = tile / (tiles_w * tiles_h);
+    if (BNB && n != bn_n) {                                      // block-uniform: this image's scale / shift row; flush the sums of the last one
+        if (bn_n >= 0 && bnb.nstride != 0) bnb_flush(bn_n);
+        bn_n = n;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            bsc[i] = bnb.scale[(long)n * bnb.nstride + cc * 8 + i];
+            bsh[i] = bnb.shift[(long)n * bnb.nstride + cc * 8 + i];
+        }
+    }
     const int trem = tile - n * tiles_w * tiles_h;
     const int y0 = (trem / tiles_w) * I1_TH, x0 = (trem % tiles_w) * I1_TW;
     const float* im = img + (size_t)n * H * W;
@@ -68,6 +113,17 @@ __global__ __launch_bounds__(256) void conv_1toC_kernel(const float* __restrict_
         halo[qy][qx] = v;
     }
     __syncthreads();
+    bf16x8 xk[BNB ? 4 : 1][BNB ? SIT : 1];                       // BNB: this lane's BatchNorm-input chunks of the four m-tiles, requested now
+    if (BNB) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int it = 0; it < SIT; ++it) {
+                const int item = min(it * 64 + lane, 16 * (C / 8) - 1);
+                const int y = min(y0 + 2 * wave + (mi >> 1), H - 1), x = min(x0 + (mi & 1) * 16 + item / (C / 8), W - 1);
+                xk[mi][it] = *(const bf16x8*)(bnb.x + (((size_t)n * H + y) * W + x) * C + cc * 8);
+            }
+    }
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {                             // wave: tile rows 2*wave, 2*wave+1 = 4 m-tiles of 16 pixels
         const int ty = 2 * wave + (mi >> 1), tx0 = (mi & 1) * 16;
@@ -100,9 +156,20 @@ __global__ __launch_bounds__(256) void conv_1toC_kernel(const float* __restrict_
             const f32x4 hi = *(const f32x4*)(o + px * LDO + cc * 8 + 4);
             const int y = y0 + ty, x = x0 + tx0 + px;
             if (y < H && x < W) {
+                float v[8] = {lo[0] + bv[0], lo[1] + bv[1], lo[2] + bv[2], lo[3] + bv[3], hi[0] + bv[4], hi[1] + bv[5], hi[2] + bv[6], hi[3] + bv[7]};
+                if (BNB) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float xf = bf2f(xk[BNB ? mi : 0][BNB ? it : 0][i]);
+                        const float d = (bnb.relu && !(xf * bsc[i] + bsh[i] > 0.f)) ? 0.f : v[i];
+                        p_dt[i] += d;
+                        p_ds[i] += d * xf;
+                        v[i] = d * bsc[i];
+                    }
+                }
                 bf16x8 ov;
-                ov[0] = f2bf(lo[0] + bv[0]); ov[1] = f2bf(lo[1] + bv[1]); ov[2] = f2bf(lo[2] + bv[2]); ov[3] = f2bf(lo[3] + bv[3]);
-                ov[4] = f2bf(hi[0] + bv[4]); ov[5] = f2bf(hi[1] + bv[5]); ov[6] = f2bf(hi[2] + bv[6]); ov[7] = f2bf(hi[3] + bv[7]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ov[i] = f2bf(v[i]);
                 *(bf16x8*)(out + (((size_t)n * H + y) * W + x) * C + cc * 8) = ov;
             }
         }
@@ -110,6 +177,30 @@ __global__ __launch_bounds__(256) void conv_1toC_kernel(const float* __restrict_
         __builtin_amdgcn_wave_barrier();
     }
     }
+    if (BNB && bn_n >= 0) bnb_flush(bn_n);
+}
+
+// conv_1toC with the BatchNorm-apply + ReLU backward folded into its store phase (see C1Bnb): the dgrad of G.output_layer
+// (model.py:379-387).  dx [N,H,W,C] bf16; dscale / dshift fp32, caller-zeroed, rows n * nstride (nstride 0: one row for the batch).
+extern "C" int ieagan_conv_1toC_bnb(const float* img, const float* tanh_y, const float* w, const void* x, const float* scale,
+                                    const float* shift, int nstride, int relu, void* dx, float* dscale, float* dshift, int N, int H,
+                                    int W, int C, int flip, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    CHECK_ARG(x && scale && shift && dx && dscale && dshift, "conv_1toC_bnb: null operand");
+    ProfScope prof("conv_1toC", 18.0 * N * H * W * (double)C, (double)N * H * W * (4.0 + 4.0 * C), st);
+    const int tiles_w = (W + I1_TW - 1) / I1_TW, tiles_h = (H + I1_TH - 1) / I1_TH;
+    const long ntl = (long)N * tiles_w * tiles_h;
+    CHECK_ARG(ntl > 0 && ntl < (1L << 31), "conv_1toC_bnb: bad geometry");
+    const long blocks = ntl < 2048 ? ntl : 2048;
+    C1Bnb b{(const bf16*)x, scale, shift, nstride, relu, dscale, dshift};
+#define L(CC) hipLaunchKernelGGL((conv_1toC_kernel<CC, true>), dim3((unsigned)blocks), dim3(256), 0, st, img, tanh_y, w, (const float*)nullptr, (bf16*)dx, N, H, W, flip, tiles_w, tiles_h, b)
+    if (C == 16) L(16);
+    else if (C == 32) L(32);
+    else if (C == 64) L(64);
+    else { ieagan_set_error("conv_1toC_bnb: C=%d not instantiated (16/32/64)", C); return IEAGAN_EINVAL; }
+#undef L
+    CHECK_LAUNCH("conv_1toC_bnb");
+    return 0;
 }
 
 extern "C" int ieagan_conv_1toC(const float* img, const float* tanh_y, const float* w, const float* bias, void* out, int N,
@@ -120,7 +211,7 @@ extern "C" int ieagan_conv_1toC(const float* img, const float* tanh_y, const flo
     const long ntl = (long)N * tiles_w * tiles_h;
     CHECK_ARG(ntl > 0 && ntl < (1L << 31), "conv_1toC: bad geometry");
     const long blocks = ntl < 4096 ? ntl : 4096;                 // persistent: ~16 blocks per CU, several tiles each
-#define L(CC) hipLaunchKernelGGL((conv_1toC_kernel<CC>), dim3((unsigned)blocks), dim3(256), 0, st, img, tanh_y, w, bias, (bf16*)out, N, H, W, flip, tiles_w, tiles_h)
+#define L(CC) hipLaunchKernelGGL((conv_1toC_kernel<CC, false>), dim3((unsigned)blocks), dim3(256), 0, st, img, tanh_y, w, bias, (bf16*)out, N, H, W, flip, tiles_w, tiles_h, C1Bnb{})
     if (C == 16) L(16);
     else if (C == 32) L(32);
     else if (C == 64) L(64);

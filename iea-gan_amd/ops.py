@@ -1073,14 +1073,13 @@ class OutputConvFn(torch.autograd.Function):
         if need[4]:
             dbias = dpre.sum().view(1)
         if need[0] or need[1] or need[2]:
-            da = torch.empty(N, Hh, Ww, C, dtype=BF16, device=dev)
-            H.call("ieagan_conv_1toC", dpre.data_ptr(), None, rec.w_plain.data_ptr(), None, da.data_ptr(), N, Hh, Ww, C, 1,
-                   H.stream())
+            # dgrad of the 3x3 conv with the BatchNorm-apply + ReLU backward in its store phase: the gradient w.r.t. the activated
+            # tensor (0.5 GB at 256x768) is never written (was: conv_1toC -> da, then prologue_bwd over da and h)
             dh = torch.empty_like(h)
             ns = 0 if scale.dim() == 1 else C
             dscale, dshift = zeros(scale.shape, dev), zeros(shift.shape, dev)
-            H.call("ieagan_prologue_bwd", da.data_ptr(), h.data_ptr(), C, scale.data_ptr(), shift.data_ptr(), ns, 1, 0,
-                   dh.data_ptr(), dscale.data_ptr(), dshift.data_ptr(), N, Hh, Ww, C, None, 0, 0, 0, H.stream())
+            H.call("ieagan_conv_1toC_bnb", dpre.data_ptr(), None, rec.w_plain.data_ptr(), h.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                   ns, 1, dh.data_ptr(), dscale.data_ptr(), dshift.data_ptr(), N, Hh, Ww, C, 1, H.stream())
         if need[3]:
             dw = sn_scratch(rec, "w", (9, C), dev)
             H.call("ieagan_wgrad_c1", dpre.data_ptr(), None, h.data_ptr(), scale.data_ptr(), shift.data_ptr(),

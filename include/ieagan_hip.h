@@ -19,7 +19,7 @@ extern "C" {
 #endif
 
 const char* ieagan_last_error(void);
-#define IEAGAN_ABI_VERSION 8        /* bumped whenever a struct layout or a signature in this header changes */
+#define IEAGAN_ABI_VERSION 9        /* bumped whenever a struct layout or a signature in this header changes */
 int ieagan_abi_version(void);        /* == IEAGAN_ABI_VERSION of the header the library was built from */
 
 /* ---- profiling hooks (bench.py): per-kernel HIP-event timing on the launch stream ---- */
@@ -184,6 +184,11 @@ int ieagan_channel_stats(const void* x, float* stats, long P, int C, void* strea
  * G.output_layer = bn + relu + conv + tanh (model.py:379-387, 487) -------------------------------- */
 int ieagan_conv_1toC(const float* img, const float* tanh_y, const float* w, const float* bias, void* out,
                      int N, int H, int W, int C, int flip, void* stream);
+/* the same as a dgrad with the BatchNorm-apply + ReLU backward of G.output_layer's prologue folded into the store phase (model.py:379-387):
+ * dx[n,h,w,c] = d * scale[n*nstride + c], d = (relu && !(x*scale+shift > 0)) ? 0 : conv;  dshift += sum d, dscale += sum d * x (caller-zeroed,
+ * rows n * nstride; nstride 0: one row for the batch).  The gradient w.r.t. the activated tensor is never materialised. */
+int ieagan_conv_1toC_bnb(const float* img, const float* tanh_y, const float* w, const void* x, const float* scale, const float* shift,
+                         int nstride, int relu, void* dx, float* dscale, float* dshift, int N, int H, int W, int C, int flip, void* stream);
 /* tanh_out: 0 = linear, 1 = tanh, 2 = tanh + the detector-unit export of model.generate (model.py:1139-1147:
  * threshold(-0.26 -> -1), 256^((r+1)/2) - 1, clamp to [0, 255], rows 3 .. H-4 only): out is then fp32 [N, H-6, W]. */
 int ieagan_conv_Cto1(const void* x, const float* scale, const float* shift, int nstride, int relu,
