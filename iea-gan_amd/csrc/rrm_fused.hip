@@ -69,18 +69,31 @@ __global__ __launch_bounds__(256) void slin_fwd_kernel(SlinFwdArgs a) {
     if (n0 >= N) return;
     const bool nok = n0 + i < N;                 // (a partly filled n-tile: N = 1 for the discriminator's logit layer)
     f32x4v acc = {0.f, 0.f, 0.f, 0.f};
-    const float* wrow = a.W + (long)(nok ? n0 + i : 0) * K + 4 * kq;
+    // The weight loads are UNCONDITIONAL: a column beyond N reads row 0 (its accumulator column is never stored), a k group beyond K
+    // re-reads the row's last group (its x operand is the zero padding of xs).  Under the old per-lane conditions the compiler
+    // waited for every load before the next one was issued: K / 16 dependent L2 round trips per wave, 19 us for a 40 x 1536 x 1536
+    // layer whose weights stream in 1 us.
+    const float* wbase = a.W + (long)(nok ? n0 + i : 0) * K;
     const float* xrow = xs + i * KS + 4 * kq;
-#pragma unroll 4
-    for (int s = 0; s < (K16 >> 4); ++s) {
+    const int nsteps = K16 >> 4;
+    auto mac = [&](int s, const f32x4v& wb) {
         const f32x4v xa = *(const f32x4v*)(xrow + 16 * s);
-        f32x4v wb = {0.f, 0.f, 0.f, 0.f};
-        if (nok && 16 * s + 4 * kq < K) wb = *(const f32x4v*)(wrow + 16 * s);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[0], wb[0], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[1], wb[1], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[2], wb[2], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[3], wb[3], acc, 0, 0, 0);
+    };
+    int s = 0;
+    for (; s + 8 <= nsteps; s += 8) {            // eight weight groups requested together (the pragma alone left the loop rolled)
+        f32x4v wb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wb[u] = *(const f32x4v*)(wbase + min(16 * (s + u) + 4 * kq, K - 4));
+        __builtin_amdgcn_sched_barrier(0);       // all eight requests first (the scheduler otherwise pairs each load with its MFMAs)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) mac(s + u, wb[u]);
+        __builtin_amdgcn_sched_barrier(0);
     }
+    for (; s < nsteps; ++s) mac(s, *(const f32x4v*)(wbase + min(16 * s + 4 * kq, K - 4)));
     const int n = n0 + i;
     if (!nok) return;
     const float bias = a.b != nullptr ? a.b[n] : 0.f;
@@ -143,22 +156,43 @@ __global__ __launch_bounds__(256) void slin_bwd_kernel(SlinBwdArgs a) {
         if ((N & 15) == 0) {
             const float* dyrow = a.dY + (long)(mok ? m0 + i : 0) * N + 4 * q;
             const float* ymrow = a.Ymask != nullptr ? a.Ymask + (long)(mok ? m0 + i : 0) * N + 4 * q : nullptr;
-#pragma unroll 2
-            for (int s = nb >> 4; s < (ne >> 4); ++s) {
-                f32x4v ga = *(const f32x4v*)(dyrow + 16 * s);
-                if (ymrow != nullptr) {
-                    const f32x4v ym = *(const f32x4v*)(ymrow + 16 * s);
+            // every load of a step is unconditional (rows / columns beyond the matrix read row 0 / column 0 and are zeroed by a
+            // select), the ReLU-mask branch is taken outside the loop and the operands of UB steps are requested before the first
+            // MFMA: N / 16 dependent round trips per wave otherwise
+            constexpr int UB = 4;
+            auto batch = [&](int s0, int cnt, bool masked) {       // cnt <= UB steps starting at s0
+                f32x4v ga[UB], ym[UB];
+                float wv[UB][4];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) ga[t] = ym[t] > 0.f ? ga[t] : 0.f;
+                for (int u = 0; u < UB; ++u) {
+                    const int s = s0 + (u < cnt ? u : 0);
+                    ga[u] = *(const f32x4v*)(dyrow + 16 * s);
+                    if (masked) ym[u] = *(const f32x4v*)(ymrow + 16 * s);
+                    const float* wp = a.W + (long)(16 * s + 4 * q) * K + (kok ? k0 + i : 0);
+                    wv[u][0] = wp[0]; wv[u][1] = wp[K]; wv[u][2] = wp[2 * (long)K]; wv[u][3] = wp[3 * (long)K];
                 }
-                if (!mok) ga = (f32x4v){0.f, 0.f, 0.f, 0.f};
-                const float* wp = a.W + (long)(16 * s + 4 * q) * K + (kok ? k0 + i : 0);
-                float w0 = wp[0], w1 = wp[K], w2 = wp[2 * (long)K], w3 = wp[3 * (long)K];
-                if (!kok) w0 = w1 = w2 = w3 = 0.f;
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[0], w0, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[1], w1, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[2], w2, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[3], w3, acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const bool live = mok && u < cnt;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        float g = ga[u][t];
+                        if (masked) g = ym[u][t] > 0.f ? g : 0.f;
+                        if (!live) g = 0.f;
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(g, kok ? wv[u][t] : 0.f, acc, 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            const int s1 = ne >> 4;
+            int s = nb >> 4;
+            if (ymrow != nullptr) {
+                for (; s + UB <= s1; s += UB) batch(s, UB, true);
+                if (s < s1) batch(s, s1 - s, true);
+            } else {
+                for (; s + UB <= s1; s += UB) batch(s, UB, false);
+                if (s < s1) batch(s, s1 - s, false);
             }
         } else {                                  // ragged N (N = 1: the logit layer): one guarded column per MFMA slot
             for (int s = 0; s < ((N + 3) >> 2); ++s) {
