@@ -14,8 +14,10 @@ namespace {
 
 constexpr int TM = 64;        // tile edge
 constexpr int TK = 16;        // reduce chunk
-constexpr int LDT = TM + 4;   // padded LDS row
+constexpr int LDK = TK + 4;   // padded LDS row: 16 consecutive rows of a fragment read land on distinct banks
 constexpr int KSPLIT = 2048;  // reduce length per Gram work item
+
+typedef float f4 __attribute__((ext_vector_type(4)));
 
 struct Operand {              // element (m, k) of a [M x Kd] operand lives at p[m * rs + k * cs]
     const float* p;
@@ -23,49 +25,58 @@ struct Operand {              // element (m, k) of a [M x Kd] operand lives at p
     int M, Kd;
 };
 
-// Stage a [TM x TK] chunk (rows m0.., reduce k0..) into LDS as s[k][m]; out-of-range -> 0.
-__device__ __forceinline__ void stage(const Operand& o, int m0, int k0, int kend, float (*s)[LDT], int tid) {
+// Stage a [TM x TK] chunk (rows m0.., reduce k0..) into LDS as s[m][k]; out-of-range -> 0.
+__device__ __forceinline__ void stage(const Operand& o, int m0, int k0, int kend, float (*s)[LDK], int tid) {
 #pragma unroll
     for (int i = 0; i < (TM * TK) / 256; ++i) {
         int e = tid + 256 * i;
         int m, k;
-        if (o.cs == 1) { m = e / TK; k = e % TK; } else { k = e / TM; m = e % TM; }
+        if (o.cs == 1) { m = e / TK; k = e % TK; } else { k = e / TM; m = e % TM; }      // consecutive threads along the contiguous axis
         int gm = m0 + m, gk = k0 + k;
         float v = 0.f;
         if (gm < o.M && gk < kend) v = o.p[(long)gm * o.rs + (long)gk * o.cs];
-        s[k][m] = v;
+        s[m][k] = v;
     }
 }
 
-// acc[4][4] (+)= A[rows ty*4.., :] . B[cols tx*4.., :]^T over the reduce range [kbeg, kend); optional row square sums of A.
+// The 64 x 64 tile on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulate).  Wave w owns rows
+// [16w, 16w+16) x all 64 columns: acc[nt][r] = C[16w + 4*kq + r][16*nt + i] for lane (i = lane & 15, kq = lane >> 4).  The four MFMAs
+// of a 16-deep chunk take the k sets {4*kq + j : kq} (j = 0..3) -- any assignment of k to the slots is valid as long as both operands
+// use it -- so a lane's operands are ONE 16-byte LDS read per fragment (A[16w + i][4kq .. 4kq+3], B[16nt + i][4kq .. 4kq+3]).
+// The VALU form of this kernel (4 x 4 register tile per thread, 8 floats of LDS traffic per 16 FMAs) ran at 13 TFLOP/s.
+// rowsq (optional): |A row|^2 of the accumulator rows of this lane, i.e. rows 16w + 4*kq + r.
 template <bool ROWSQ>
-__device__ __forceinline__ void tile_gemm(const Operand& A, const Operand& B, int m0, int n0, int kbeg, int kend, float (*As)[LDT],
-                                          float (*Bs)[LDT], float acc[4][4], float rowsq[4], int tid) {
-    const int ty = tid / 16, tx = tid % 16;
+__device__ __forceinline__ void tile_gemm(const Operand& A, const Operand& B, int m0, int n0, int kbeg, int kend, float (*As)[LDK],
+                                          float (*Bs)[LDK], f4 (&acc)[4], float (&rowsq)[4], int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    float rs_part = 0.f;                          // this lane's share of |A[16w + i]|^2
     for (int k0 = kbeg; k0 < kend; k0 += TK) {
         stage(A, m0, k0, kend, As, tid);
         stage(B, n0, k0, kend, Bs, tid);
         __syncthreads();
+        const f4 a = *(const f4*)&As[16 * wave + i][4 * kq];
+        if (ROWSQ) rs_part += a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
 #pragma unroll
-        for (int k = 0; k < TK; ++k) {
-            const float4 a = *reinterpret_cast<const float4*>(&As[k][ty * 4]);
-            const float4 b = *reinterpret_cast<const float4*>(&Bs[k][tx * 4]);
-            const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+        for (int nt = 0; nt < 4; ++nt) {
+            const f4 b = *(const f4*)&Bs[16 * nt + i][4 * kq];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
-                if (ROWSQ) rowsq[i] = fmaf(av[i], av[i], rowsq[i]);
-            }
+            for (int j = 0; j < 4; ++j) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc[nt], 0, 0, 0);
         }
         __syncthreads();
+    }
+    if (ROWSQ) {
+        rs_part += __shfl_xor(rs_part, 16, 64);
+        rs_part += __shfl_xor(rs_part, 32, 64);   // every lane with this i now holds |A[16w + i]|^2
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rowsq[r] = __shfl(rs_part, 4 * kq + r, 64);
     }
 }
 
 __global__ __launch_bounds__(256) void ortho_gram_kernel(const float* __restrict__ flat, const long* __restrict__ table,
                                                          const int* __restrict__ tiles, float* __restrict__ gram) {
-    __shared__ __attribute__((aligned(16))) float As[TK][LDT];
-    __shared__ __attribute__((aligned(16))) float Bs[TK][LDT];
+    __shared__ __attribute__((aligned(16))) float As[TM][LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[TM][LDK];
     const int* t = tiles + 4 * blockIdx.x;
     const long* L = table + 4 * t[0];
     const float* W = flat + L[0];
@@ -75,23 +86,25 @@ __global__ __launch_bounds__(256) void ortho_gram_kernel(const float* __restrict
     const int M = rowform ? R : K, red = rowform ? K : R;
     Operand X = rowform ? Operand{W, (long)K, 1, M, red} : Operand{W, 1, (long)K, M, red};
     const int m0 = t[1] * TM, n0 = t[2] * TM, kbeg = t[3] * KSPLIT, kend = min(red, kbeg + KSPLIT);
-    float acc[4][4] = {}, dummy[4];
+    f4 acc[4] = {};
+    float dummy[4];
     tile_gemm<false>(X, X, m0, n0, kbeg, kend, As, Bs, acc, dummy, threadIdx.x);
-    const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, kq = lane >> 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int gi = m0 + ty * 4 + i, gj = n0 + tx * 4 + j;
-            if (gi < M && gj < M && !(rowform && gi == gj)) atomicAdd(&G[(long)gi * M + gj], acc[i][j]);
+        for (int r = 0; r < 4; ++r) {
+            const int gi = m0 + 16 * wave + 4 * kq + r, gj = n0 + 16 * nt + i;
+            if (gi < M && gj < M && !(rowform && gi == gj)) atomicAdd(&G[(long)gi * M + gj], acc[nt][r]);
         }
 }
 
 __global__ __launch_bounds__(256) void ortho_apply_kernel(const float* __restrict__ flat, float* __restrict__ grad,
                                                           const long* __restrict__ table, const int* __restrict__ tiles,
                                                           const float* __restrict__ gram, float coef) {
-    __shared__ __attribute__((aligned(16))) float As[TK][LDT];
-    __shared__ __attribute__((aligned(16))) float Bs[TK][LDT];
+    __shared__ __attribute__((aligned(16))) float As[TM][LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[TM][LDK];
     const int* t = tiles + 4 * blockIdx.x;
     const long* L = table + 4 * t[0];
     const float* W = flat + L[0];
@@ -100,7 +113,8 @@ __global__ __launch_bounds__(256) void ortho_apply_kernel(const float* __restric
     const float* G = gram + L[3];
     const bool rowform = R <= K;
     const int m0 = t[1] * TM, n0 = t[2] * TM;
-    float acc[4][4] = {}, rowsq[4] = {0.f, 0.f, 0.f, 0.f};
+    f4 acc[4] = {};
+    float rowsq[4] = {0.f, 0.f, 0.f, 0.f};
     if (rowform) {      // out[i,c] = sum_j P[i,j] W[j,c]:  A = P [R x R], B(c, j) = W[j, c]
         Operand A{G, (long)R, 1, R, R}, B{W, 1, (long)K, K, R};
         tile_gemm<false>(A, B, m0, n0, 0, R, As, Bs, acc, rowsq, threadIdx.x);
@@ -108,16 +122,17 @@ __global__ __launch_bounds__(256) void ortho_apply_kernel(const float* __restric
         Operand A{W, (long)K, 1, R, K}, B{G, (long)K, 1, K, K};
         tile_gemm<true>(A, B, m0, n0, 0, K, As, Bs, acc, rowsq, threadIdx.x);
     }
-    const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, kq = lane >> 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int gi = m0 + ty * 4 + i, gc = n0 + tx * 4 + j;
+        for (int r = 0; r < 4; ++r) {
+            const int gi = m0 + 16 * wave + 4 * kq + r, gc = n0 + 16 * nt + i;
             if (gi < R && gc < K) {
-                long idx = (long)gi * K + gc;
-                float v = acc[i][j];
-                if (!rowform) v -= rowsq[i] * W[idx];
+                const long idx = (long)gi * K + gc;
+                float v = acc[nt][r];
+                if (!rowform) v -= rowsq[r] * W[idx];
                 dW[idx] += coef * v;
             }
         }
