@@ -28,6 +28,11 @@ __device__ __forceinline__ bool in_cut(int h, int w, int H, int W, int ox, int o
     return h >= r0 && h <= r1 && w >= c0 && w <= c1;
 }
 
+// Row-based mapping (round 3): a block walks rows h = blockIdx.x, + gridDim.x, ..., a thread four consecutive columns -- 16-byte
+// accesses on the aligned side, no per-pixel 64-bit division (the flat one-float-per-thread form with p / W per pixel took 120 us
+// for a 31 MB image batch, 0.5 TB/s).  Source indices are clamped (unconditional loads), validity is a select.
+typedef float af4 __attribute__((ext_vector_type(4)));
+
 template <int MODE>
 __global__ __launch_bounds__(256) void aug_sum_kernel(const float* __restrict__ x, AugDraws d, float* __restrict__ out, int H, int W) {
     __shared__ float red[4];
@@ -38,15 +43,28 @@ __global__ __launch_bounds__(256) void aug_sum_kernel(const float* __restrict__ 
     if (MODE == 1) {
         tx = (int)d.tx[n]; ty = (int)d.ty[n]; ox = (int)d.ox[n]; oy = (int)d.oy[n];
     }
+    const bool w4ok = (W & 3) == 0;
     float s = 0.f;
-    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
-        float v = xi[p];
-        if (MODE == 1) {
-            const int h = (int)(p / W), w = (int)(p - (long)h * W);
-            const int hs = h + tx, ws = w + ty;
-            if (hs < 0 || hs >= H || ws < 0 || ws >= W || in_cut(h, w, H, W, ox, oy)) v = 0.f;
+    for (int h = blockIdx.x; h < H; h += gridDim.x) {
+        const float* row = xi + (long)h * W;
+        const bool hok = MODE == 0 || (h + tx >= 0 && h + tx < H);
+        for (int w0 = threadIdx.x * 4; w0 < W; w0 += 1024) {
+            float v[4];
+            if (w4ok) {
+                const af4 t = *(const af4*)(row + w0);
+                v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = (w0 + j < W) ? row[w0 + j] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int w = w0 + j;
+                bool keep = w < W;
+                if (MODE == 1) keep = keep && hok && w + ty >= 0 && w + ty < W && !in_cut(h, w, H, W, ox, oy);
+                s += keep ? v[j] : 0.f;
+            }
         }
-        s += v;
     }
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -63,15 +81,29 @@ __global__ __launch_bounds__(256) void diffaug_fwd_kernel(const float* __restric
     const int tx = (int)d.tx[n], ty = (int)d.ty[n], ox = (int)d.ox[n], oy = (int)d.oy[n];
     const float* xi = x + (long)n * HW;
     float* oi = out + (long)n * HW;
-    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
-        const int h = (int)(p / W), w = (int)(p - (long)h * W);
-        const int hs = h + tx, ws = w + ty;
-        float v = 0.f;
-        if (hs >= 0 && hs < H && ws >= 0 && ws < W && !in_cut(h, w, H, W, ox, oy)) {
-            const float xb = xi[(long)hs * W + ws] + b;
-            v = (xb - m) * c + m;
+    const bool w4ok = (W & 3) == 0;
+    for (int h = blockIdx.x; h < H; h += gridDim.x) {
+        const int hs = h + tx;
+        const bool hok = hs >= 0 && hs < H;
+        const float* srow = xi + (long)min(max(hs, 0), H - 1) * W;
+        float* orow = oi + (long)h * W;
+        for (int w0 = threadIdx.x * 4; w0 < W; w0 += 1024) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int w = w0 + j, ws = w + ty;
+                const float xb = srow[min(max(ws, 0), W - 1)] + b;          // (the source column may be unaligned: four scalar loads)
+                const bool keep = hok && ws >= 0 && ws < W && !in_cut(h, w, H, W, ox, oy);
+                v[j] = keep ? (xb - m) * c + m : 0.f;
+            }
+            if (w4ok) {
+                *(af4*)(orow + w0) = (af4){v[0], v[1], v[2], v[3]};
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (w0 + j < W) orow[w0 + j] = v[j];
+            }
         }
-        oi[p] = v;
     }
 }
 
@@ -85,18 +117,39 @@ __global__ __launch_bounds__(256) void diffaug_bwd_kernel(const float* __restric
     const int tx = (int)d.tx[n], ty = (int)d.ty[n], ox = (int)d.ox[n], oy = (int)d.oy[n];
     const float* gi = gout + (long)n * HW;
     float* oi = gx + (long)n * HW;
-    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
-        const int hs = (int)(p / W), ws = (int)(p - (long)hs * W);
-        const int h = hs - tx, w = ws - ty;
-        float v = 0.f;
-        if (h >= 0 && h < H && w >= 0 && w < W && !in_cut(h, w, H, W, ox, oy)) v = gi[(long)h * W + w];
-        oi[p] = c * v + mterm;
+    const bool w4ok = (W & 3) == 0;
+    for (int hs = blockIdx.x; hs < H; hs += gridDim.x) {
+        const int h = hs - tx;
+        const bool hok = h >= 0 && h < H;
+        const float* grow = gi + (long)min(max(h, 0), H - 1) * W;
+        float* orow = oi + (long)hs * W;
+        for (int w0 = threadIdx.x * 4; w0 < W; w0 += 1024) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ws = w0 + j, w = ws - ty;
+                const float g = grow[min(max(w, 0), W - 1)];
+                const bool keep = hok && w >= 0 && w < W && !in_cut(h, w, H, W, ox, oy);
+                v[j] = c * (keep ? g : 0.f) + mterm;
+            }
+            if (w4ok) {
+                *(af4*)(orow + w0) = (af4){v[0], v[1], v[2], v[3]};
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (w0 + j < W) orow[w0 + j] = v[j];
+            }
+        }
     }
 }
 
 static inline dim3 img_grid(int N, long HW) {
     long b = (HW + 255) / 256;
     if (b > 256) b = 256;
+    return dim3((unsigned)b, N);
+}
+static inline dim3 row_grid(int N, int H) {        // the row-based kernels: one block per 1..4 rows of an image
+    int b = H < 128 ? H : 128;
     return dim3((unsigned)b, N);
 }
 
@@ -106,8 +159,8 @@ extern "C" int ieagan_diffaug_fwd(const float* x, const float* bright, const flo
     hipStream_t st = (hipStream_t)stream;
     AugDraws d{bright, contrast, tx, ty, ox, oy};
     ProfScope prof("diffaug_fwd", 0.0, 12.0 * N * H * W, st);
-    hipLaunchKernelGGL((aug_sum_kernel<0>), img_grid(N, (long)H * W), dim3(256), 0, st, x, d, sums, H, W);
-    hipLaunchKernelGGL(diffaug_fwd_kernel, img_grid(N, (long)H * W), dim3(256), 0, st, x, d, (const float*)sums, out, H, W);
+    hipLaunchKernelGGL((aug_sum_kernel<0>), row_grid(N, H), dim3(256), 0, st, x, d, sums, H, W);
+    hipLaunchKernelGGL(diffaug_fwd_kernel, row_grid(N, H), dim3(256), 0, st, x, d, (const float*)sums, out, H, W);
     CHECK_LAUNCH("diffaug_fwd");
     return 0;
 }
@@ -117,8 +170,8 @@ extern "C" int ieagan_diffaug_bwd(const float* gout, const float* contrast, cons
     hipStream_t st = (hipStream_t)stream;
     AugDraws d{nullptr, contrast, tx, ty, ox, oy};
     ProfScope prof("diffaug_bwd", 0.0, 12.0 * N * H * W, st);
-    hipLaunchKernelGGL((aug_sum_kernel<1>), img_grid(N, (long)H * W), dim3(256), 0, st, gout, d, gsums, H, W);
-    hipLaunchKernelGGL(diffaug_bwd_kernel, img_grid(N, (long)H * W), dim3(256), 0, st, gout, d, (const float*)gsums, gx, H, W);
+    hipLaunchKernelGGL((aug_sum_kernel<1>), row_grid(N, H), dim3(256), 0, st, gout, d, gsums, H, W);
+    hipLaunchKernelGGL(diffaug_bwd_kernel, row_grid(N, H), dim3(256), 0, st, gout, d, (const float*)gsums, gx, H, W);
     CHECK_LAUNCH("diffaug_bwd");
     return 0;
 }
