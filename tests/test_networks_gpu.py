@@ -515,6 +515,8 @@ def test_wgrad_side_stream_two_stage_and_fused_1x1_backward_do_not_change_the_st
     for k in pa:
         if float(pa[k].norm()) < 1e-3 * gmax:          # (biases in front of a BatchNorm and the like: zero up to noise)
             continue
+        if pa[k].numel() < 8:                           # a scalar (output_layer.2.bias = the sum of 7.8M signed terms): ONE pair of runs gives
+            continue                                    # no usable estimate of its own noise (observed 7e-2 in one pair, 1.9 in the next)
         nk, dk = rel_l2(pc[k], pb[k]), rel_l2(pb[k], pa[k])
         if dk > max(4.0 * nk, 2e-2):
             bad.append((k, dk, nk))
