@@ -122,6 +122,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs a, int 
     load_A(g0, cur);
     load_epi(g0, pm, pr);
     int aff_n = -1;
+    float rsc[8], rsh[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rsc[i] = rsh[i] = 0.f;
     for (int g = g0; g < g1; ++g) {
         const long gbase = (long)g * GP;
         const int n_img = (int)(gbase / HW);                       // launcher: HW % GP == 0 -> one image per group
@@ -130,6 +133,14 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs a, int 
             stage_aff(aff_s, a.src, n_img, Cin);
             aff_n = n_img;
             __syncthreads();
+            if (KS == 1) {          // Cin <= 32: a lane's channel chunk never changes -- its scale / shift stay in registers for the image
+                const int c0 = (lg * 8) % AFF_MAXC;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    rsc[i] = aff_s[c0 + i];
+                    rsh[i] = aff_s[AFF_MAXC + c0 + i];
+                }
+            }
         }
         const long wbase = gbase + wave * (MT * 16);
         // group g's operands (requested one iteration ago) have landed.  NOT vmcnt(0): on gfx9 the counter also holds the STORES of
@@ -158,7 +169,15 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs a, int 
                             float v[8];
 #pragma unroll
                             for (int i = 0; i < 8; ++i) v[i] = bf2f(af[i]);
-                            xform8<AFF, RELU>(v, a.src, n_img, (ks * 32 + lg * 8) % AFF_MAXC, aff_s);
+                            if (KS == 1) {          // (four LDS reads and their wait per m-tile otherwise)
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) {
+                                    v[i] = v[i] * rsc[i] + rsh[i];
+                                    if (RELU) v[i] = fmaxf(v[i], 0.f);
+                                }
+                            } else {
+                                xform8<AFF, RELU>(v, a.src, n_img, (ks * 32 + lg * 8) % AFF_MAXC, aff_s);
+                            }
 #pragma unroll
                             for (int i = 0; i < 8; ++i) af[i] = f2bf(v[i]);
                             if (ks * 32 + lg * 8 >= Cin) af = zero8();     // K padding must stay zero after the shift
