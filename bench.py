@@ -23,6 +23,7 @@ One JSON line on stdout (rank 0):
 """
 import argparse
 import contextlib
+import faulthandler
 import io
 import json
 import math
@@ -94,14 +95,19 @@ def physical_cores():
         return None
 
 
-def leave():
-    """Exit without interpreter teardown once the record is printed -- unless a profiler is attached (rocprofv3 writes its
-    files from exit handlers)."""
-    sys.stdout.flush()
-    sys.stderr.flush()
-    if any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
-        return
-    os._exit(0)
+def cpu_threads():
+    """Threads for the CPU leg: the cores this process may really use -- min(affinity mask, physical cores, cgroup CPU quota)."""
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(float(q) / float(per)))
+    except (OSError, ValueError):
+        pass
+    phys = physical_cores()
+    n = min(x for x in (avail, phys, quota) if x)
+    return n, {"host_logical_cpus_available": avail, "host_physical_cores": phys, "cgroup_cpu_quota": quota}
 
 
 def cpu_baseline(cfg, mode="sub", threads=None):
@@ -111,8 +117,8 @@ def cpu_baseline(cfg, mode="sub", threads=None):
     by 40 / 8 (the conv work, > 95 % of the CPU time, is linear in the sensor count)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ieagan_oracle as O
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads = threads or min(avail, 32)
+    auto, host = cpu_threads()
+    threads = threads or auto
     torch.set_num_threads(threads)
     sensors = 40 if mode == "full" else 8
     c = dict(cfg, device="cpu", events_per_step=1)
@@ -139,8 +145,8 @@ def cpu_baseline(cfg, mode="sub", threads=None):
               f"(warm-up {times[0]:.1f} s)" if mode == "full" else
               f"one oracle train step (fp32, PyTorch CPU) at 256x768 on {sensors} of 40 sensors: {dt:.1f} s, "
               f"scaled x{40 // sensors} to a full event")
-    res = {"value": 1.0 / (dt * 40.0 / sensors), "unit": "events/s", "cores": threads, "kind": "port", "sample": sample,
-           "host_logical_cpus_available": avail, "host_physical_cores": physical_cores()}
+    torch.set_num_threads(1)           # park the intra-op pool: nothing after the CPU leg needs it (and it must be idle at exit)
+    res = {"value": 1.0 / (dt * 40.0 / sensors), "unit": "events/s", "cores": threads, "kind": "port", "sample": sample, **host}
     if mode != "full":
         # next to the bounded sample: the full 40-sensor step as last recorded with --cpu-baseline full (committed, not re-timed here)
         for name in CPU_FULL_FILES:
@@ -308,6 +314,7 @@ def measure(cfg, args, rank, world, local, tag):
         dp_slack = {k: [round(v, 3) for v in vs] for k, vs in sync.slack_ms().items()}
         sync.trace = False
     parallel.set_context(None)
+    train.close()           # graphs, side streams, queued spectral-norm passes: released here, in order, not at interpreter teardown
     if args.trace_losses and rank == 0:
         for i, o in enumerate(trace):
             print(f"[{tag}] step {i}: " + "  ".join(f"{k} {v:.4f}" for k, v in o.items()), file=sys.stderr)
@@ -383,8 +390,12 @@ def main():
     ap.add_argument("--lr", type=float, default=None, help="override G_lr / D_lr of the benchmark configuration (tuning aid)")
     ap.add_argument("--serial-wgrad", action="store_true", help="weight-gradient launches on the main stream (tuning aid: step time = sum of "
                                                                "all launches + gaps; the difference to the kernel-time total is launch overhead)")
+    ap.add_argument("--only", choices=("configs1",), default=None, help="skip configs[3] / configs[4] (tuning aid; same as --no-configs3)")
     ap.add_argument("--conv-dtype", choices=("bf16", "fp8"), default=None, help="run the headline workload with this conv_dtype (tuning aid)")
     args = ap.parse_args()
+    faulthandler.enable()
+    if args.only:
+        args.no_configs3 = True
 
     import _hip
     import parallel
@@ -414,8 +425,8 @@ def main():
     m = measure(cfg, args, rank, world, local, "configs1")
     if rank != 0:
         if world > 1:
-            dist.destroy_process_group()
-        leave()                   # (as rank 0 below: no interpreter teardown after the measurement)
+            parallel.shutdown()
+        return
     E, h, w, dt, steps = m["E"], m["h"], m["w"], m["dt"], m["steps"]
     desc1 = (f"BASELINE configs[1]: 1 event (40x1x{h}x{w}) per GPU per step, hinge loss only, RRM on, DiffAugment on, ortho reg + "
              "Adam + EMA in the timed region, fp32 master weights, 4 synthetic events in rotation")
@@ -433,11 +444,16 @@ def main():
            "git_head": git_head()}
     sat = [o for o in m["timed_losses"] if not (o["D_loss_real"] > 0.0 and o["D_loss_fake"] > 0.0)]
     res["hinge_unsaturated_in_every_timed_step"] = not sat          # both D hinge terms > 0: every backward pass carries non-zero gradients
+    res["config"]["hinge_unsaturated_in_every_timed_step"] = not sat
+    res["config"]["losses_last_step"] = m["out"]
     if m["dp_slack"] is not None:
         res["dp_exchange_slack_ms"] = dict(m["dp_slack"], note="per step: ms between the side stream finishing a network's all-reduce + update and "
                                            "the main stream reaching its wait for it (positive: fully hidden; negative: the main stream stalled)")
     if m["recs"]:
         kernel_report(res, m, args)
+        if res.get("roofline") and res.get("roofline_conv_mfma"):
+            res["roofline"]["conv_mfma_frac"] = res["roofline_conv_mfma"]["frac"]
+            res["roofline"]["conv_mfma_kernel"] = res["roofline_conv_mfma"]["kernel"]
     if world == 1 and not args.no_configs3 and not args.only_configs3:
         m3 = measure(cfg_for(3), args, rank, world, local, "configs3")
         r3 = {"workload": desc3, "value": m3["E"] * m3["steps"] / m3["dt"], "unit": "events/s", "steps": m3["steps"],
@@ -455,12 +471,12 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(cfg_for(1), args.cpu_baseline)
     print(json.dumps(res))
+    sys.stdout.flush()
     if dist.is_initialized():
-        dist.destroy_process_group()
-    # The record is out: leave without interpreter teardown.  (One run of the default command died with SIGSEGV AFTER printing
-    # its complete record, somewhere in the destruction order of HIP graphs / streams / the CPU baseline's worker threads at
-    # exit; a benchmark's exit status should not depend on that.)
-    leave()
+        parallel.shutdown()
+    # Normal interpreter exit (round 3 left through os._exit after one run had died with SIGSEGV behind its record): every
+    # measure() has released its graphs / streams through train.close() while the HIP runtime was alive, the CPU leg's
+    # intra-op pool is parked, and faulthandler would print the Python stack of any fault that is left.
 
 
 if __name__ == "__main__":

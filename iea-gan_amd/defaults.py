@@ -48,4 +48,10 @@ def default_config() -> dict:
     c.update(hip_graph=False)            # replay the train step from captured HIP graphs (one graph; three in data-parallel runs)
     c.update(conv_dtype="bf16")          # 'fp8': e4m3 MFMA operands in the forward of the C >= 64 3x3 layers (BASELINE configs[4])
     c.update(events_per_step=1)          # E events of batch_size images per GPU and step (BASELINE configs[3])
+    # data-parallel runs: evaluate D(x_real) before G(z) -> D(fake) so that G's gradient exchange hides under the real pass (DESIGN
+    # section 7).  The two D passes then see swapped spectral-norm iterates relative to the reference / a single-GPU run
+    # (tolerance-level): `--dp_real_first false` keeps the reference order on N GPUs; the value is written to the run
+    # metadata with the rest of the configuration.
+    c.update(dp_real_first=True)
+    c.update(sn_prefetch=True)           # spectral-norm passes issued ahead of time on a side stream (single-GPU default step)
     return c

@@ -543,6 +543,14 @@ def wgrad_stream(device) -> "torch.cuda.Stream":
     return _WGRAD_STREAMS[key]
 
 
+def release_device_caches():
+    """Drop the module-level device objects (zero-pool chunks, side streams, placeholder tensors): part of an orderly shutdown
+    (train_fns ``train.close()``); everything is re-created on demand."""
+    _ZEROS.reset()
+    _WGRAD_STREAMS.clear()
+    _PLACEHOLDERS.clear()
+
+
 FUSE_BN_BACKWARD = True   # BatchNorm-apply backward inside the dgrad epilogue (False: the stand-alone prologue_bwd pass)
 
 

@@ -191,6 +191,7 @@ def run(cfg):
     checkpoint()
     if rank == 0:
         print(f"done: {state['itr']} iterations, weights under {os.path.join(run_dir, 'weights')}")
+    train.close()                       # graphs / side streams released before the process group and the interpreter go away
     parallel.shutdown()                 # barrier + destroy_process_group: no rank leaves while another is in a collective
     return state
 

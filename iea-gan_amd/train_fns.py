@@ -416,5 +416,32 @@ def GAN_training_function(G, D, GD, z_, y_, ema, state_dict, config, device):
         st["static"] = None
         return whole_step()
 
+    def close():
+        """Release what the step holds on the device, in a defined order, while the HIP runtime is still alive: join the side
+        streams (gradient exchange, spectral-norm prefetch, weight gradients), drop the captured graphs (their executables and the
+        private memory pools they pin), the queued spectral-norm passes, the static input copies and the cached scratch.  Without
+        it these objects die during interpreter teardown, in whatever order the module globals are cleared -- a captured graph
+        destroyed after its streams / the process group is the exit-time fault bench.py used to mask with os._exit.  ``train`` may
+        be called again afterwards (graphs are re-captured)."""
+        import gc
+        cuda = torch.cuda.is_available()
+        if sync is not None and cuda:
+            sync.wait_all()
+        if cuda:
+            torch.cuda.synchronize()
+        for r in (whole, *seg, *([seg_real] if seg_real is not None else [])):
+            r.reset()
+        for net in (G, D):
+            plan = getattr(net, "_plan", None)
+            if plan is not None:
+                plan["bank"].discard_prefetched()
+        st.update(x=None, y=None, static=None, noise=None, emb_real=None, sn_stream=None)
+        st.pop("real_out", None)
+        ops.release_device_caches()
+        gc.collect()
+        if cuda:
+            torch.cuda.synchronize()
+
     train.step_tensor = step_eager_tensor
+    train.close = close
     return train

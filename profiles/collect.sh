@@ -10,7 +10,10 @@ TAG="${1:-r02}"; HEAD="${2:-unknown}"
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-python bench.py --steps 10 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err || { tail -c 2000 gpurun_out/${TAG}_bench.err; python -c "import json,sys; json.loads(open('gpurun_out/${TAG}_bench.json').read().strip().splitlines()[-1])" || exit 1; }
+python bench.py --steps 10 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+rc=$?
+echo "$rc" > gpurun_out/${TAG}_bench.rc          # the exit status is evidence too (normal interpreter teardown, no masking)
+if [ "$rc" -ne 0 ]; then tail -c 3000 gpurun_out/${TAG}_bench.err; exit 1; fi
 echo "bench done"
 rm -rf gpurun_out/${TAG}_trace
 rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_trace -o t --output-format csv -- python3 bench.py --steps 16 --no-cpu-baseline --no-configs3 --no-kernel-timing > gpurun_out/${TAG}_trace.log 2>&1
