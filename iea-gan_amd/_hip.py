@@ -35,7 +35,7 @@ class ConvDesc(C.Structure):
                 ("taps", C.c_int), ("Kpad", C.c_int), ("src", SrcDesc), ("w", vp), ("bias", vp),
                 ("ra", vp), ("Cra", C.c_int), ("Ca", C.c_int), ("ra_rs", C.c_int), ("ra_scale", C.c_float), ("rb", vp),
                 ("Crb", C.c_int), ("mask", vp), ("out", vp), ("stats", vp), ("n_per_event", C.c_int), ("flags", C.c_int),
-                ("bnb_scale", vp), ("bnb_shift", vp), ("bnb_nstride", C.c_int), ("bnb_relu", C.c_int)]
+                ("bnb_scale", vp), ("bnb_shift", vp), ("bnb_nstride", C.c_int), ("bnb_relu", C.c_int), ("stats_slots", C.c_int)]
 
 
 class WgradDesc(C.Structure):
@@ -48,7 +48,13 @@ class Conv1x1BwdDesc(C.Structure):
     _fields_ = [("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int), ("Kpad", C.c_int),
                 ("Kpad2", C.c_int), ("src", SrcDesc), ("g", vp), ("Cg", C.c_int), ("y", vp), ("dstat", vp), ("n_per_event", C.c_int),
                 ("geff_out", vp), ("w_bwd", vp), ("lg", vp), ("lC", C.c_int), ("lCa", C.c_int), ("lmode", C.c_int), ("dx", vp),
-                ("out_mode", C.c_int), ("bn_acc", vp), ("dw", vp), ("partials", vp), ("colsum", vp), ("flags", C.c_int)]
+                ("out_mode", C.c_int), ("bn_acc", vp), ("dw", vp), ("partials", vp), ("colsum", vp), ("flags", C.c_int), ("bn_slots", C.c_int)]
+
+
+class Conv3x3BwdDesc(C.Structure):
+    _fields_ = [("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int), ("Kpad", C.c_int), ("src", SrcDesc), ("g", vp), ("Cg", C.c_int),
+                ("y", vp), ("dstat", vp), ("n_per_event", C.c_int), ("w_bwd", vp), ("dx", vp), ("bn_acc", vp), ("dw", vp), ("partials", vp),
+                ("colsum", vp), ("flags", C.c_int), ("bn_slots", C.c_int)]
 
 
 class DStemDesc(C.Structure):
@@ -62,7 +68,7 @@ class ProfRec(C.Structure):
                 ("flops", C.c_double), ("bytes", C.c_double), ("bytes_min", C.c_double)]
 
 
-ABI_VERSION = 9            # include/ieagan_hip.h: IEAGAN_ABI_VERSION
+ABI_VERSION = 10           # include/ieagan_hip.h: IEAGAN_ABI_VERSION
 i, f, l = C.c_int, C.c_float, C.c_long
 _SIGS = {
     "ieagan_abi_version": [],
@@ -75,11 +81,17 @@ _SIGS = {
     "ieagan_conv1x1_bwd": [C.POINTER(Conv1x1BwdDesc), vp],
     "ieagan_conv1x1_bwd_workspace": [C.POINTER(Conv1x1BwdDesc)],
     "ieagan_conv1x1_bwd_supported": [i, i, i, i],
+    "ieagan_conv3x3_bwd": [C.POINTER(Conv3x3BwdDesc), vp],
+    "ieagan_conv3x3_bwd_workspace": [C.POINTER(Conv3x3BwdDesc)],
+    "ieagan_conv3x3_bwd_supported": [i, i, i, i, i, i, i],
+    "ieagan_conv3x3_bwd_slots": [C.POINTER(Conv3x3BwdDesc)],
+    "ieagan_conv1x1_bwd_slots": [C.POINTER(Conv1x1BwdDesc)],
+    "ieagan_conv_stats_slots": [C.POINTER(ConvDesc)],
     "ieagan_d_stem_fwd": [C.POINTER(DStemDesc), vp],
     "ieagan_d_stem_bwd": [C.POINTER(DStemDesc), vp],
     "ieagan_effgrad": [vp, vp, vp, vp, vp, l, i, i, vp],
     "ieagan_prologue_bwd": [vp, vp, i, vp, vp, i, i, i, vp, vp, vp, i, i, i, i, vp, i, i, i, vp],
-    "ieagan_bn_finalize_fwd": [vp, f, vp, vp, i, i, f, f, i, vp, vp, vp, vp, vp, i, i, i, vp],
+    "ieagan_bn_finalize_fwd": [vp, f, vp, vp, i, i, f, f, i, vp, vp, vp, vp, vp, i, i, i, i, vp],
     "ieagan_bn_finalize_bwd": [vp, vp, vp, i, i, vp, f, i, vp, vp, i, vp, i, i, i, i, vp],
     "ieagan_res_bwd": [vp, i, vp, i, i, i, i, i, i, vp],
     "ieagan_nchw_to_nhwc": [vp, vp, vp, i, i, i, i, vp],

@@ -38,8 +38,11 @@ static std::vector<ProfEvt> g_prof;
 static bool g_prof_tags = false;
 bool prof_tags_on() { return g_prof_on && g_prof_tags; }
 
+static thread_local ConvPlanCtx g_plan = {false, 0};
+ConvPlanCtx& conv_plan_ctx() { return g_plan; }
+
 ProfScope::ProfScope(const char* name, double flops, double bytes, hipStream_t s, const char* tag, double bytes_min) : slot(-1), stream(s) {
-    if (!g_prof_on) return;
+    if (!g_prof_on || g_plan.on) return;
     ProfEvt e{std::string(name), nullptr, nullptr, flops, bytes, bytes_min < 0.0 ? bytes : bytes_min};
     if (g_prof_tags && tag != nullptr) e.name += std::string(" ") + tag;
     if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
@@ -107,6 +110,17 @@ extern "C" int ieagan_prof_collect(ieagan_prof_rec* out, int cap) {
 extern "C" int ieagan_conv_forward(const ieagan_conv_desc* d, void* stream) {
     CHECK_ARG(d != nullptr && d->src.x != nullptr && d->w != nullptr && d->out != nullptr, "conv_forward: null pointer");
     return conv_gather_launch(*d, (hipStream_t)stream);
+}
+
+extern "C" int ieagan_conv_stats_slots(const ieagan_conv_desc* d) {
+    CHECK_ARG(d != nullptr, "conv_stats_slots: null pointer");
+    g_plan.on = true;
+    g_plan.slots = -1;
+    const int rc = conv_gather_launch(*d, nullptr);
+    g_plan.on = false;
+    if (rc < 0) return rc;
+    CHECK_ARG(g_plan.slots > 0, "conv_stats_slots: the dispatch reached no launch site");
+    return g_plan.slots;
 }
 
 extern "C" int ieagan_conv_wgrad(const ieagan_wgrad_desc* d, int use_tr_read, void* stream) {

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __res
                                        const float* __restrict__ bias, int ld, int plus_one, float eps, float momentum,
                                        int training, float* __restrict__ run_mean, float* __restrict__ run_var,
                                        float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_rstd,
-                                       int N, int C, int E) {
+                                       int N, int C, int E, int R) {
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
@@ -242,8 +242,9 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __res
         float mean, var;
         if (training) {
             float s1 = 0.f, s2 = 0.f;
-            const float* se = stats + (long)e * STAT_REPL * 2 * C;
-            for (int r = lane; r < STAT_REPL; r += 64) {
+            // R slots, folded in a fixed order (lane-strided partial sums, then the wave butterfly): bit-reproducible for ANY slot count
+            const float* se = stats + (long)e * R * 2 * C;
+            for (int r = lane; r < R; r += 64) {
                 s1 += se[(long)r * 2 * C + c];
                 s2 += se[(long)r * 2 * C + C + c];
             }
@@ -279,14 +280,16 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __res
 extern "C" int ieagan_bn_finalize_fwd(const float* stats, float count, const float* gain, const float* bias, int ld,
                                       int plus_one, float eps, float momentum, int training, float* run_mean,
                                       float* run_var, float* scale, float* shift, float* mean_rstd, int N, int C, int E,
-                                      void* stream) {
+                                      int repl, void* stream) {
     CHECK_ARG(!training || stats != nullptr, "bn_finalize: training mode needs batch statistics");
+    CHECK_ARG(repl >= 0, "bn_finalize: bad slot count %d", repl);
+    if (repl == 0) repl = STAT_REPL;
     if (E < 1) E = 1;
     CHECK_ARG(N % E == 0, "bn_finalize: %d images are not %d whole events", N, E);
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof("bn_finalize_fwd", 0.0, 0.0, st);
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, stats, count, gain, bias, ld, plus_one, eps,
-                       momentum, training, run_mean, run_var, scale, shift, mean_rstd, N, C, E);
+                       momentum, training, run_mean, run_var, scale, shift, mean_rstd, N, C, E, repl);
     CHECK_LAUNCH("bn_finalize_fwd");
     return 0;
 }
@@ -360,7 +363,7 @@ extern "C" int ieagan_bn_finalize_bwd(const float* dscale, const float* dshift, 
                                       int ldd, float* dstat, int N, int C, int E, int acc_repl, void* stream) {
     if (E < 1) E = 1;
     CHECK_ARG(N % E == 0, "bn_finalize_bwd: %d images are not %d whole events", N, E);
-    CHECK_ARG(acc_repl >= 0 && acc_repl <= 64, "bn_finalize_bwd: bad replica count %d", acc_repl);
+    CHECK_ARG(acc_repl >= 0 && acc_repl <= 4096, "bn_finalize_bwd: bad replica count %d", acc_repl);
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof("bn_finalize_bwd", 0.0, 0.0, st);
     hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, dscale, dshift, gain, ld, plus_one,
@@ -451,11 +454,27 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
             s2 += f * f;
         }
     }
-    if (stats != nullptr && c0 + tx < C) {
-        const int event = npe > 0 ? n / npe : 0;
-        float* st = stats + ((long)event * STAT_REPL + (blockIdx.x + blockIdx.z) % STAT_REPL) * 2 * C;
-        atomicAdd(st + c0 + tx, s1);
-        atomicAdd(st + C + c0 + tx, s2);
+    if (stats != nullptr) {
+        // one slot per (image of the event, 32-pixel block): the 8 pixel phases (ty) of a channel are folded through LDS in a fixed
+        // order, the slot has a single adder -> bit-reproducible statistics
+        __syncthreads();
+        tile[ty][tx] = s1;
+        tile[8 + ty][tx] = s2;
+        __syncthreads();
+        if (ty == 0 && c0 + tx < C) {
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                a1 += tile[j][tx];
+                a2 += tile[8 + j][tx];
+            }
+            const int ipe = npe > 0 ? npe : (int)gridDim.z;
+            const int event = n / ipe;
+            const long slot = (long)(n - event * ipe) * gridDim.x + blockIdx.x;
+            float* st = stats + ((long)event * ipe * gridDim.x + slot) * 2 * C;
+            atomicAdd(st + c0 + tx, a1);
+            atomicAdd(st + C + c0 + tx, a2);
+        }
     }
 }
 

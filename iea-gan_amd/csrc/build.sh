@@ -10,7 +10,7 @@ mkdir -p "${OBJ}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wno-unused-value -ffp-contract=fast"
 pids=()
-for f in api conv_igemm conv_wgrad conv1x1_stream conv1x1_tile conv1x1_bwd conv3x3_lds conv3x3_ws attention bn_elem conv_c1 d_stem sn aug_optim small_ops rrm_fused ortho; do
+for f in api conv_igemm conv_wgrad conv1x1_stream conv1x1_tile conv1x1_bwd conv3x3_bwd conv3x3_lds conv3x3_ws attention bn_elem conv_c1 d_stem sn aug_optim small_ops rrm_fused ortho; do
   [ -f "${HERE}/${f}.hip" ] || continue
   if [ ! -f "${OBJ}/${f}.o" ] || [ "${HERE}/${f}.hip" -nt "${OBJ}/${f}.o" ] || [ -n "$(find "${HERE}" "${HERE}/../../include" -name '*.h' -newer "${OBJ}/${f}.o" 2>/dev/null)" ]; then
     ${HIPCC} ${FLAGS} -c "${HERE}/${f}.hip" -o "${OBJ}/${f}.o" &

@@ -390,7 +390,9 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_bwd_kernel(Bwd1Args a, int t
                 x1 += red[(wv * CIN + tt) * 2 + 0];
                 x2 += red[(wv * CIN + tt) * 2 + 1];
             }
-            float* st = a.bn_acc + ((long)n * BNB_REPL + bid % BNB_REPL) * 2 * CIN;
+            // slot = this block's index inside its image when bn_slots == blocks per image (one adder per address: bit-reproducible)
+            const int R = a.bn_slots > 0 ? a.bn_slots : BNB_REPL;
+            float* st = a.bn_acc + ((long)n * R + bid % R) * 2 * CIN;
             atomicAdd(st + tt, x1);
             atomicAdd(st + CIN + tt, x2);
         }
@@ -474,6 +476,7 @@ static int b1_plan(const Bwd1Args& a, B1Plan& p) {
     }
     CHECK_ARG(a.dx != nullptr || a.dw != nullptr, "conv1x1_bwd: nothing to compute");
     CHECK_ARG((a.flags & ~(IEAGAN_B1_OCC2 | IEAGAN_B1_OCC3 | IEAGAN_B1_TP32)) == 0, "conv1x1_bwd: unknown flag bits 0x%x", a.flags);
+    CHECK_ARG(a.bn_slots >= 0, "conv1x1_bwd: bad bn_slots %d", a.bn_slots);
     CHECK_ARG(a.colsum == nullptr || a.dw != nullptr, "conv1x1_bwd: colsum rides on the weight gradient");
     const int tpi = a.H * a.W / TP;
     // ONE round of persistent blocks: every resident slot (256 CUs x blocks per CU) gets one block, whole blocks per image, the four
@@ -500,6 +503,13 @@ extern "C" long ieagan_conv1x1_bwd_workspace(const ieagan_conv1x1_bwd_desc* d) {
     B1Plan p;
     if (d == nullptr || b1_plan(*d, p) != 0) return 0;
     return p.ws_elems;
+}
+
+extern "C" int ieagan_conv1x1_bwd_slots(const ieagan_conv1x1_bwd_desc* d) {
+    B1Plan p;
+    if (d == nullptr) return IEAGAN_EINVAL;
+    const int rc = b1_plan(*d, p);
+    return rc != 0 ? rc : p.bpi;
 }
 
 extern "C" int ieagan_conv1x1_bwd_supported(int Cin, int Cout, int rs, int affine) { return b1_shape_ok(Cin, Cout, rs, affine != 0) ? 1 : 0; }

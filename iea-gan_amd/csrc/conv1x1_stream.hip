@@ -282,6 +282,7 @@ static void stream_launch_one(const ConvArgs& a, hipStream_t st) {
     if (gpb > gpe) gpb = gpe;
     const int bpe = (gpe + gpb - 1) / gpb;
     const int nblk = bpe * n_events;
+    CONV_PLAN_POINT(bpe, )
     hipLaunchKernelGGL((conv1x1_stream_kernel<AFF, RELU, NT, KS, MT>), dim3(nblk, (a.Cout + 16 * NT - 1) / (16 * NT)), dim3(256), 0, st, a,
                        gpb, gpe, nblk, bpe);
 }

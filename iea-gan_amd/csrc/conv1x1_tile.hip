@@ -207,8 +207,10 @@ template <bool AFF, bool RELU, int RS, bool BNB>
 static int tile_dispatch(const ConvArgs& a, hipStream_t st) {
     const long M = (long)a.N * a.H * a.W;
     const unsigned gx = (unsigned)((M + 127) / 128);
+    const int n_events_t = (a.stats != nullptr && a.n_per_event > 0) ? a.N / a.n_per_event : 1;
 #define TL(NTV, KCV)                                                                                                                    \
     {                                                                                                                                   \
+        CONV_PLAN_POINT((int)(gx / n_events_t), 1)                                                                                      \
         hipLaunchKernelGGL((conv1x1_tile_kernel<AFF, RELU, RS, NTV, KCV, BNB>), dim3(gx, a.Cout / (NTV * 16)), dim3(256), 0, st, a);     \
         return 1;                                                                                                                       \
     }

@@ -292,6 +292,7 @@ static int lds_launch(const ConvArgs& a, hipStream_t st) {
         if (tpb > tpe) tpb = tpe;                                                                                                  \
         const int bpe = (tpe + tpb - 1) / tpb;                                                                                     \
         const int nblk = bpe * n_events;                                                                                           \
+        CONV_PLAN_POINT(bpe, 1)                                                                                                    \
         const size_t lds = (size_t)NTV * 16 * 9 * CINV * 2 + (size_t)(THV + 2) * (TWV + 2) * CINV * 2;                             \
         const bool full = a.H % THV == 0 && a.W % TWV == 0;                                                                        \
         auto kern = full ? conv3x3_lds_kernel<AFF, RELU, RS, CINV, NTV, THV, TWV, NWV, BNB, true>                                  \
@@ -670,6 +671,7 @@ static int lds_fp8_launch(const ConvArgs& a, hipStream_t st) {
         if (tpb > tpe) tpb = tpe;                                                                                                  \
         const int bpe = (tpe + tpb - 1) / tpb;                                                                                     \
         const int nblk = bpe * n_events;                                                                                           \
+        CONV_PLAN_POINT(bpe, 1)                                                                                                    \
         const size_t halo = (size_t)(THV + 2) * (TWV + 2) * CINV, epi = (size_t)NWV * EpiLds<NTV>::FLOATS * 4;                     \
         const size_t lds = (size_t)NTV * 16 * 9 * CINV + (halo > epi ? halo : epi);                                                \
         if (a.flags & IEAGAN_CONV_FP8_NOSCALE)                                                                                     \

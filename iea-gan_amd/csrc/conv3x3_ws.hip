@@ -292,6 +292,7 @@ static int ws_launch_f(const ConvArgs& a, hipStream_t st) {
         size_t tail = (size_t)NCWV * EpiLds<NTV>::FLOATS * 4;                                                                \
         if (tail < (size_t)NCWV * STATS_SX_FLOATS * 4) tail = (size_t)NCWV * STATS_SX_FLOATS * 4;                             \
         const size_t lds = (size_t)NTV * 16 * (KPV * 2 + 16) + 2 * (size_t)(WS_H + 2) * (WS_W + 2) * (CINV * 2 + 16) + tail;  \
+        CONV_PLAN_POINT(bpe, 1)                                                                                              \
         auto kern = conv3x3_ws_kernel<AFF, RELU, RS, CINV, BNB, MPF, NCWV, FULL>;                                            \
         static bool attr_set = false;                                                                                        \
         if (!attr_set) {                                                                                                     \

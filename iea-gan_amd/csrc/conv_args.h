@@ -17,3 +17,13 @@ int conv3x3_lds_launch(const ConvArgs& a, hipStream_t st);       // 1 = launched
 int conv3x3_ws_launch(const ConvArgs& a, hipStream_t st);         // 1 = launched, 0 = not applicable (caller falls back to conv3x3_halo)
 int conv1x1_stream_launch(const ConvArgs& a, hipStream_t st);     // 1 = launched, 0 = not applicable (caller falls back to conv_gather)
 int conv1x1_tile_launch(const ConvArgs& a, hipStream_t st);       // 1 = launched, 0 = not applicable (caller falls back to conv_gather)
+
+// Planning calls (ieagan_conv_stats_slots): the dispatch runs exactly as in a real call, but every launch site records its blocks per
+// statistics group here and returns instead of launching.  Thread-local (api.hip).
+struct ConvPlanCtx { bool on; int slots; };
+ConvPlanCtx& conv_plan_ctx();
+#define CONV_PLAN_POINT(BPE, RET)                      \
+    if (conv_plan_ctx().on) {                          \
+        conv_plan_ctx().slots = (BPE);                 \
+        return RET;                                    \
+    }

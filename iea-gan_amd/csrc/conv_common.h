@@ -77,8 +77,9 @@ __device__ __forceinline__ void stats_flush(const ConvArgs& a, float (&s1)[8], f
             x1 += red[(wv * NT * 16 + t) * 2 + 0];
             x2 += red[(wv * NT * 16 + t) * 2 + 1];
         }
-        // (the per-image accumulators of the BatchNorm-backward epilogue see ~10x fewer adders per address: 8 replicas)
-        const int R = (a.bnb_scale != nullptr) ? BNB_REPL : STAT_REPL;
+        // slots per group (ieagan_conv_desc.stats_slots): == the launch's blocks per group -> one adder per address, bit-reproducible sums;
+        // 0: the legacy replica counts (several adders per slot, order-dependent rounding)
+        const int R = a.stats_slots > 0 ? a.stats_slots : ((a.bnb_scale != nullptr) ? BNB_REPL : STAT_REPL);
         float* st = a.stats + ((long)event * R + replica % R) * 2 * a.Cout;
         atomicAdd(st + n_base + t, x1);
         atomicAdd(st + a.Cout + n_base + t, x2);

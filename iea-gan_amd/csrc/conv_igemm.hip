@@ -163,6 +163,7 @@ static int launch_gather_nt(const ConvArgs& a0, hipStream_t st) {
     const bool laff = AFF && ((long)a.H * a.W) % 128 == 0 && a.Cin <= AFF_MAXC;
 #define GATHER_LAUNCH(NTV, GY)                                                                                                  \
     {                                                                                                                           \
+        CONV_PLAN_POINT((int)(gx / ((a.stats != nullptr && a.n_per_event > 0) ? (unsigned)(a.N / a.n_per_event) : 1u)), 0)       \
         if (AFF && laff) hipLaunchKernelGGL((conv_gather_kernel<TAPS, AFF, RELU, RS, NTV, AFF, BNB>), dim3(gx, GY), dim3(256), 0, st, a); \
         else hipLaunchKernelGGL((conv_gather_kernel<TAPS, AFF, RELU, RS, NTV, false, BNB>), dim3(gx, GY), dim3(256), 0, st, a);      \
     }
@@ -496,6 +497,7 @@ static int launch_halo_nt(const ConvArgs& a, hipStream_t st) {
         if ((PFV) > 0) lds += (size_t)NTV * 16 * (a.Kpad * 2 + 16);                                          \
         const int bpe = (tpe + tp - 1) / tp;                                                                 \
         const int nblk = bpe * n_events;                                                                     \
+        CONV_PLAN_POINT(bpe, 0)                                                                              \
         hipLaunchKernelGGL((conv3x3_halo_kernel<AFF, RELU, RS, NTV, PFV, CINV, BNB>), dim3(nblk, (a.Cout + 16 * NTV - 1) / (16 * NTV)), \
                            dim3(256), lds, st, a, tiles_w, tiles_h, tpe, tp, nblk, bpe);                     \
     }
@@ -597,6 +599,7 @@ int conv_gather_launch(const ConvArgs& a, hipStream_t st) {
         }
         else { ieagan_set_error("conv: 1x1 with upsampled source is not instantiated"); return IEAGAN_EINVAL; }
     }
+    if (conv_plan_ctx().on) return rc;
     CHECK_LAUNCH("conv_forward");
     return rc;
 }

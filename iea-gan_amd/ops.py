@@ -72,9 +72,11 @@ def zeros(shape, device) -> torch.Tensor:
     return _ZEROS.take(n, device).view(shape)
 
 
-def new_stats(C: int, device, events: int = 1) -> torch.Tensor:
-    """Zeroed per-event replicated (sum, sumsq) accumulators: [E, STAT_REPL, 2, C]."""
-    return zeros((events, STAT_REPL, 2, C), device)
+def new_stats(C: int, device, events: int = 1, slots: int = STAT_REPL) -> torch.Tensor:
+    """Zeroed per-event (sum, sumsq) accumulators: [E, slots, 2, C].  ``slots`` = the producing launch's blocks per event makes every slot
+    a single-adder address (bit-reproducible sums; ``_conv_launch(stats=True)`` sizes it that way); the default is the legacy replica
+    count (several adders per slot: the float-atomic order then decides the last bits)."""
+    return zeros((events, slots, 2, C), device)
 
 
 # When True (set by the train step around ``backward()``), gradients of spectrally normalised weights
@@ -439,10 +441,11 @@ class BNFinalizeFn(torch.autograd.Function):
         scale = torch.empty(N, C, dtype=torch.float32, device=dev)
         shift = torch.empty(N, C, dtype=torch.float32, device=dev)
         mr = torch.empty(events, 2, C, dtype=torch.float32, device=dev)
+        repl = int(stats.shape[1]) if stats is not None else 0
         H.call("ieagan_bn_finalize_fwd", H.ptr(stats), float(count), gb.data_ptr() + 4 * col_gain,
                gb.data_ptr() + 4 * col_bias, ld, 1, float(eps), float(momentum), int(training), run_mean.data_ptr(),
-               run_var.data_ptr(), scale.data_ptr(), shift.data_ptr(), mr.data_ptr(), N, C, events, H.stream())
-        ctx.bank, ctx.cols, ctx.C, ctx.count, ctx.training, ctx.events = bank, (col_gain, col_bias), C, count, training, events
+               run_var.data_ptr(), scale.data_ptr(), shift.data_ptr(), mr.data_ptr(), N, C, events, repl, H.stream())
+        ctx.bank, ctx.cols, ctx.C, ctx.count, ctx.training, ctx.events, ctx.repl = bank, (col_gain, col_bias), C, count, training, events, repl
         ctx.has_stats = stats is not None
         ctx.save_for_backward(gb, mr)
         return scale, shift
@@ -460,7 +463,7 @@ class BNFinalizeFn(torch.autograd.Function):
         repl = 0
         if acc is not None:        # the consumer conv's dgrad folded the apply backward in: replicated per-image accumulators
             ctx.link.acc = None
-            dscale, dshift, repl = acc, acc, H.BNB_REPL
+            dscale, dshift, repl = acc, acc, int(acc.shape[1])
         else:
             dscale = dscale.contiguous() if dscale is not None else torch.zeros(N, C, device=gb.device)
             dshift = dshift.contiguous() if dshift is not None else torch.zeros(N, C, device=gb.device)
@@ -469,7 +472,7 @@ class BNFinalizeFn(torch.autograd.Function):
                gbuf.data_ptr() + 4 * ctx.cols[1], ld, dstat.data_ptr(), N, C, E, repl, H.stream())
         bank.pending -= 1
         dgb = gbuf if bank.pending == 0 else None
-        dstats = dstat.unsqueeze(1).expand(E, STAT_REPL, 2, C) if (ctx.has_stats and ctx.training) else None
+        dstats = dstat.unsqueeze(1).expand(E, ctx.repl, 2, C) if (ctx.has_stats and ctx.training) else None
         return dstats, dgb, None, None, None, None, None, None, None, None, None, None, None, None
 
 
@@ -487,10 +490,11 @@ class BNFinalizePlainFn(torch.autograd.Function):
         scale = torch.empty(shape, dtype=torch.float32, device=dev)
         shift = torch.empty(shape, dtype=torch.float32, device=dev)
         mr = torch.empty(events, 2, C, dtype=torch.float32, device=dev)
+        repl = int(stats.shape[1]) if stats is not None else 0
         H.call("ieagan_bn_finalize_fwd", H.ptr(stats), float(count), gain.data_ptr(), bias.data_ptr(), 0, 0, float(eps),
                float(momentum), int(training), run_mean.data_ptr(), run_var.data_ptr(), scale.data_ptr(),
-               shift.data_ptr(), mr.data_ptr(), rows, C, events, H.stream())
-        ctx.count, ctx.training, ctx.has_stats, ctx.events, ctx.rows = count, training, stats is not None, events, rows
+               shift.data_ptr(), mr.data_ptr(), rows, C, events, repl, H.stream())
+        ctx.count, ctx.training, ctx.has_stats, ctx.events, ctx.rows, ctx.repl = count, training, stats is not None, events, rows, repl
         ctx.save_for_backward(gain, mr)
         return scale, shift
 
@@ -508,7 +512,7 @@ class BNFinalizePlainFn(torch.autograd.Function):
         H.call("ieagan_bn_finalize_bwd", dscale.data_ptr(), dshift.data_ptr(), gain.data_ptr(), 0, 0, mr.data_ptr(),
                float(ctx.count), int(ctx.training), dgain.data_ptr(), dbias.data_ptr(), 0, dstat.data_ptr(), rows, C, E, 0,
                H.stream())
-        dstats = dstat.unsqueeze(1).expand(E, STAT_REPL, 2, C) if (ctx.has_stats and ctx.training) else None
+        dstats = dstat.unsqueeze(1).expand(E, ctx.repl, 2, C) if (ctx.has_stats and ctx.training) else None
         return dstats, dgain, dbias, None, None, None, None, None, None, None, None
 
 
@@ -518,12 +522,25 @@ class BNFinalizePlainFn(torch.autograd.Function):
 def _conv_launch(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu, N, Hc, Wc, Cin, Cout, taps, kpad, w, bias,
                  ra, Cra, Ca, ra_rs, rb, Crb, mask, out, stats, ra_scale=1.0, npe=0, flags=0, bnb=None):
     """``bnb`` = (scale, shift, nstride, relu): BatchNorm-apply backward fused into this (dgrad) launch -- ``mask`` is then the
-    BatchNorm input x and ``stats`` the per-image accumulators [N, BNB_REPL, 2, Cout] (``npe`` = 1), see include/ieagan_hip.h."""
+    BatchNorm input x and ``stats`` the per-image accumulators [N, slots, 2, Cout] (``npe`` = 1), see include/ieagan_hip.h.
+    ``stats``: None | a caller-zeroed tensor [groups, slots, 2, Cout] (tests; block b of a group adds into slot b % slots) | True: the
+    buffer is allocated here with slots = the blocks per statistics group this very launch will use (ieagan_conv_stats_slots: the
+    library plans the dispatch without launching) -- every slot then has ONE adder and the sums are bit-reproducible.  Returns the
+    statistics tensor."""
     bs, bt, bn, br = (H.ptr(bnb[0]), H.ptr(bnb[1]), int(bnb[2]), int(bool(bnb[3]))) if bnb is not None else (None, None, 0, 0)
+    alloc = stats is True
     d = H.ConvDesc(N, Hc, Wc, Cin, Cout, taps, kpad, H.src_desc(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu),
                    H.ptr(w), H.ptr(bias), H.ptr(ra), Cra, Ca, ra_rs, float(ra_scale), H.ptr(rb), Crb, H.ptr(mask),
-                   H.ptr(out), H.ptr(stats), int(npe), int(flags), bs, bt, bn, br)
+                   H.ptr(out), 16 if alloc else H.ptr(stats), int(npe), int(flags), bs, bt, bn, br,
+                   0 if (alloc or stats is None) else int(stats.shape[1]))
+    if alloc:
+        slots = H.lib().ieagan_conv_stats_slots(d)
+        if slots <= 0:
+            raise RuntimeError(f"ieagan_conv_stats_slots failed ({slots}): {H.lib().ieagan_last_error().decode()}")
+        stats = zeros((N // npe if npe else 1, slots, 2, Cout), out.device)
+        d.stats, d.stats_slots = stats.data_ptr(), slots
     H.call("ieagan_conv_forward", d, H.stream())
+    return stats
 
 
 USE_TR_READ = True        # ds_read_b64_tr_b16 operand reads in conv_wgrad (False: scalar LDS reads)
@@ -689,11 +706,17 @@ def _conv1x1_backward_fused(ctx, dout, dstats):
     if conv_sc:
         lmode = 0                                   # the deposited gradient lives at the block OUTPUT (= pooled) resolution
     dx = torch.empty((N, Hc, Wc, Cin) if out_mode == 1 else (N, Hs, Ws, Cin), dtype=BF16, device=dev)
-    acc = zeros((N, H.BNB_REPL, 2, Cin), dev) if has_aff else None
     d = H.Conv1x1BwdDesc(N, Hc, Wc, Cin, Cout, rec.kpad, rec.kpad2, H.src_desc(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu),
                          g.data_ptr(), Cg, H.ptr(out) if eff else None, H.ptr(dstat), N // ctx.events, H.ptr(geff), rec.w_bwd.data_ptr(),
-                         H.ptr(lg), lC or 0, lCa or 0, lmode or 0, dx.data_ptr(), out_mode, H.ptr(acc), dwp.data_ptr(), None, H.ptr(colsum),
-                         FUSE_1X1_FLAGS)
+                         H.ptr(lg), lC or 0, lCa or 0, lmode or 0, dx.data_ptr(), out_mode, 16 if has_aff else None, dwp.data_ptr(), None, H.ptr(colsum),
+                         FUSE_1X1_FLAGS, 0)
+    acc = None
+    if has_aff:         # per-image BatchNorm accumulators: one slot per block of the image (single adder: bit-reproducible)
+        d.bn_slots = H.lib().ieagan_conv1x1_bwd_slots(d)
+        if d.bn_slots <= 0:
+            raise RuntimeError(f"ieagan_conv1x1_bwd_slots failed: {H.lib().ieagan_last_error().decode()}")
+        acc = zeros((N, d.bn_slots, 2, Cin), dev)
+        d.bn_acc = acc.data_ptr()
     ws_n = H.lib().ieagan_conv1x1_bwd_workspace(d)
     if ws_n > 0:
         ws = torch.empty(ws_n, dtype=torch.float32, device=dev)
@@ -736,6 +759,79 @@ def _conv1x1_backward_fused(ctx, dout, dstats):
     return dx, dW, dbias, dscale, dshift, d_ra, d_rb, None, None, None, None, None, None, None, None, None, None, None
 
 
+# The whole backward of a 3x3 convolution with Cin = Cout = 16 / 32 on a large map in ONE launch (csrc/conv3x3_bwd.hip): effgrad on load + dgrad
+# with the prologue backward (ReLU mask / BatchNorm apply / 2x2 sum of an up-sampled source) in its store phase + wgrad + bias column sums
+# from the same LDS tiles.  False: the separate launches (tests compare the two).
+FUSE_3X3_BACKWARD = True
+FUSE_3X3_MIN_PIXELS = 1 << 16
+
+
+def _fused_3x3_eligible(ctx, dout, dstats):
+    if not FUSE_3X3_BACKWARD:
+        return False
+    taps, rs, relu, Ca, ra_rs, nstride, Hc, Wc = ctx.cfg
+    rec = ctx.rec
+    need = ctx.needs_input_grad
+    has_bias, has_aff, has_ra, has_rb = ctx.has
+    res_out, res_in = ctx.links
+    x = ctx.saved_tensors[0]
+    N = x.shape[0]
+    if taps != 9 or rec.cin != rec.out or not need[0] or not need[1] or has_ra or has_rb or res_out is not None or res_in is not None:
+        return False
+    if N * Hc * Wc < FUSE_3X3_MIN_PIXELS or rec.kpad != rec.kpad2 or x.shape[3] != rec.cin:
+        return False
+    if not H.lib().ieagan_conv3x3_bwd_supported(rec.cin, rs, int(has_aff), int(bool(relu)), int(dstats is not None), Hc, Wc):
+        return False
+    if has_aff and ctx.events > 1 and nstride == 0:
+        return False
+    st = dout.stride()
+    return dout.is_contiguous() or (st[3] == 1 and st[2] % 8 == 0 and st[2] >= rec.out and st[1] == Wc * st[2] and
+                                    st[0] == Hc * Wc * st[2] and dout.data_ptr() % 16 == 0)
+
+
+def _conv3x3_backward_fused(ctx, dout, dstats):
+    x, weight, scale, shift, out = ctx.saved_tensors
+    rec = ctx.rec
+    taps, rs, relu, Ca, ra_rs, nstride, Hc, Wc = ctx.cfg
+    has_bias, has_aff, has_ra, has_rb = ctx.has
+    N, Hs, Ws, Cx = x.shape
+    C = rec.cin
+    dev = x.device
+    need = ctx.needs_input_grad
+    Cg = C if dout.is_contiguous() else dout.stride()[2]
+    eff = dstats is not None
+    dstat = dstats[:, 0].contiguous() if eff else None
+    colsum = sn_scratch(rec, "b", (STAT_REPL, C), dev) if (has_bias and need[2]) else None
+    dwp = sn_scratch(rec, "w", (C, rec.kpad), dev)
+    dx = torch.empty(N, Hs, Ws, C, dtype=BF16, device=dev)
+    d = H.Conv3x3BwdDesc(N, Hc, Wc, C, rec.kpad, H.src_desc(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu), dout.data_ptr(), Cg,
+                         H.ptr(out) if eff else None, H.ptr(dstat), N // ctx.events, rec.w_bwd.data_ptr(), dx.data_ptr(), 16 if has_aff else None,
+                         dwp.data_ptr(), None, H.ptr(colsum), 0, 0)
+    ws = torch.empty(H.lib().ieagan_conv3x3_bwd_workspace(d), dtype=torch.float32, device=dev)
+    d.partials = ws.data_ptr()
+    acc = None
+    if has_aff:         # per-image BatchNorm accumulators: one slot per block of the image (single adder: bit-reproducible)
+        d.bn_slots = H.lib().ieagan_conv3x3_bwd_slots(d)
+        if d.bn_slots <= 0:
+            raise RuntimeError(f"ieagan_conv3x3_bwd_slots failed: {H.lib().ieagan_last_error().decode()}")
+        acc = zeros((N, d.bn_slots, 2, C), dev)
+        d.bn_acc = acc.data_ptr()
+    H.call("ieagan_conv3x3_bwd", d, H.stream())
+    dscale = dshift = None
+    if has_aff:
+        bn_link = getattr(scale, "_bn_link", None)
+        if bn_link is not None:
+            bn_link.acc = acc
+            dscale = dshift = _placeholder(scale)
+        else:                       # stand-alone use (tests): fold the replicated per-image accumulators here
+            sums = acc.sum(1)
+            dshift, dscale = sums[:, 0], sums[:, 1]
+            if nstride == 0:
+                dshift, dscale = dshift.sum(0), dscale.sum(0)
+    dW, dbias = sn_backward(dwp, weight, rec, colsum, ctx.bias_ref)
+    return dx, dW, dbias, dscale, dshift, None, None, None, None, None, None, None, None, None, None, None, None, None
+
+
 class ConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, scale, shift, ra, rb, rec, taps, rs, relu, Ca, ra_rs, want_stats, res_out, res_in, events=1, flags=0):
@@ -745,14 +841,13 @@ class ConvFn(torch.autograd.Function):
         assert N % events == 0, (N, events)
         Hc, Wc = (2 * Hs, 2 * Ws) if rs == 1 else (Hs // 2, Ws // 2) if rs == 2 else (Hs, Ws)
         out = torch.empty(N, Hc, Wc, Cout, dtype=BF16, device=x.device)
-        stats = new_stats(Cout, x.device, events) if want_stats else None
         nstride = 0 if (scale is None or scale.dim() == 1) else scale.shape[1]
         # per-layer kernel-selection flags of the conv descriptor (H.CONV_FP8: e4m3 MFMA operands, conv_dtype='fp8' of the owning
         # network -- BASELINE configs[4]); they only mean something to the C = 64 / 128 3x3 kernels and ride along to the dgrad launch
         flags = int(flags) if (taps == 9 and Cin in (64, 128)) else 0
-        _conv_launch(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu, N, Hc, Wc, Cin, Cout, taps, rec.kpad, rec.w_fwd,
-                     bias, ra, ra.shape[-1] if ra is not None else 0, Ca, ra_rs, rb,
-                     rb.shape[-1] if rb is not None else 0, None, out, stats, npe=N // events, flags=flags)
+        stats = _conv_launch(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu, N, Hc, Wc, Cin, Cout, taps, rec.kpad, rec.w_fwd,
+                             bias, ra, ra.shape[-1] if ra is not None else 0, Ca, ra_rs, rb,
+                             rb.shape[-1] if rb is not None else 0, None, out, True if want_stats else None, npe=N // events, flags=flags)
         ctx.events, ctx.flags = events, flags
         ctx.rec, ctx.cfg = rec, (taps, rs, relu, Ca, ra_rs, nstride, Hc, Wc)
         ctx.ra_shape = ra.shape if ra is not None else None
@@ -766,6 +861,8 @@ class ConvFn(torch.autograd.Function):
     def backward(ctx, dout, dstats):
         if _fused_1x1_eligible(ctx, dout, dstats):
             return _conv1x1_backward_fused(ctx, dout, dstats)
+        if _fused_3x3_eligible(ctx, dout, dstats):
+            return _conv3x3_backward_fused(ctx, dout, dstats)
         x, weight, scale, shift, out = ctx.saved_tensors
         rec = ctx.rec
         taps, rs, relu, Ca, ra_rs, nstride, Hc, Wc = ctx.cfg
@@ -846,11 +943,10 @@ class ConvFn(torch.autograd.Function):
                 # BatchNorm apply + ReLU backward inside the dgrad epilogue: dx is written directly, the per-(n, c) sums go to
                 # replicated per-image accumulators that bn_finalize_bwd folds (no da tensor, no stand-alone pass over da / x)
                 dx = torch.empty(N, Hs, Ws, Cin, dtype=BF16, device=dev)
-                acc = zeros((N, H.BNB_REPL, 2, Cin), dev)
                 up = res_in is not None and lmode == 1          # shortcut gradient at double resolution: 2x2 SUM = 4 * average
-                _conv_launch(g, Cg, Hc, Wc, 0, None, None, 0, False, N, Hc, Wc, Cout, Cin, taps, rec.kpad2, rec.w_bwd, None,
-                             lg, lC or 0, lCa or 0, 2 if up else 0, None, 0, x, dx, acc, ra_scale=4.0 if up else 1.0, npe=1,
-                             bnb=(scale, shift, nstride, relu), flags=ctx.flags)
+                acc = _conv_launch(g, Cg, Hc, Wc, 0, None, None, 0, False, N, Hc, Wc, Cout, Cin, taps, rec.kpad2, rec.w_bwd, None,
+                                   lg, lC or 0, lCa or 0, 2 if up else 0, None, 0, x, dx, True, ra_scale=4.0 if up else 1.0, npe=1,
+                                   bnb=(scale, shift, nstride, relu), flags=ctx.flags)
                 bn_link.acc = acc
                 dscale = dshift = _placeholder(scale)
             elif res_in is not None and (fuse_mask or (plain and rs == 0)):
@@ -1023,7 +1119,7 @@ class DStemFn(torch.autograd.Function):
             colsum = sn_scratch(recsc, "b", (STAT_REPL, 32), dev)
             d = H.Conv1x1BwdDesc(N, Hp, Wp, 32, 32, recsc.kpad, recsc.kpad2, H.src_desc(p0, 32, Hp, Wp, 0, None, None, 0, False), dsc.data_ptr(), Cg,
                                  None, None, N, None, recsc.w_bwd.data_ptr(), H.ptr(lg), lC if lg is not None else 0, lCa if lg is not None else 0, 0,
-                                 dpt.data_ptr(), 1, None, dwp.data_ptr(), None, colsum.data_ptr(), FUSE_1X1_FLAGS)
+                                 dpt.data_ptr(), 1, None, dwp.data_ptr(), None, colsum.data_ptr(), FUSE_1X1_FLAGS, 0)
             ws_n = H.lib().ieagan_conv1x1_bwd_workspace(d)
             if ws_n > 0:
                 ws = torch.empty(ws_n, dtype=torch.float32, device=dev)
@@ -1117,7 +1213,8 @@ class ToNHWCFn(torch.autograd.Function):
         N, C, Hh, Ww = x.shape
         x = x.contiguous().float()
         out = torch.empty(N, Hh, Ww, C, dtype=BF16, device=x.device)
-        stats = new_stats(C, x.device, events) if want_stats else None
+        # one statistics slot per (image of the event, 32-pixel block): a single adder each (bit-reproducible sums)
+        stats = new_stats(C, x.device, events, (N // events) * ((Hh * Ww + 31) // 32)) if want_stats else None
         H.call("ieagan_nchw_to_nhwc", x.data_ptr(), out.data_ptr(), H.ptr(stats), N, C, Hh * Ww, N // events, H.stream())
         ctx.events = events
         ctx.save_for_backward(out if want_stats else None)

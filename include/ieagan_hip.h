@@ -19,7 +19,7 @@ extern "C" {
 #endif
 
 const char* ieagan_last_error(void);
-#define IEAGAN_ABI_VERSION 9        /* bumped whenever a struct layout or a signature in this header changes */
+#define IEAGAN_ABI_VERSION 10       /* bumped whenever a struct layout or a signature in this header changes */
 int ieagan_abi_version(void);        /* == IEAGAN_ABI_VERSION of the header the library was built from */
 
 /* ---- profiling hooks (bench.py): per-kernel HIP-event timing on the launch stream ---- */
@@ -79,6 +79,11 @@ typedef struct {
     const float* bnb_shift;
     int bnb_nstride;      /* image stride of bnb_scale / bnb_shift (0: per-channel rows shared by all images)  */
     int bnb_relu;
+    /* Slots per statistics group: `stats` is fp32 [E][stats_slots][2][Cout] (BatchNorm-backward mode: [N][stats_slots][2][Cout]); block b of
+     * a group adds into slot b % stats_slots.  With stats_slots == ieagan_conv_stats_slots(d) every slot has exactly ONE adder, so the
+     * sums (and everything computed from them) are bit-reproducible run to run -- the order of float atomics on a shared address is not.
+     * 0: the legacy replica counts (32; 8 in BatchNorm-backward mode). */
+    int stats_slots;
 } ieagan_conv_desc;
 #define IEAGAN_CONV_FORCE_GATHER 1
 #define IEAGAN_CONV_FP8 4              /* forward and dgrad launches of the C = 64 / 128 3x3 layers with OCP e4m3 MFMA operands (per-slice
@@ -87,6 +92,9 @@ typedef struct {
 #define IEAGAN_CONV_FP8_NOSCALE 8      /* with IEAGAN_CONV_FP8 (benchmarks): the non-scaled K = 32 fp8 MFMA instead of the block-scaled K = 128 form */
 #define IEAGAN_CONV_NO_LDS_WEIGHTS 2   /* tests / benchmarks: C = 64 / 128 3x3 layers through conv3x3_halo instead of conv3x3_lds */
 int ieagan_conv_forward(const ieagan_conv_desc* d, void* stream);
+/* blocks per statistics group of the launch ieagan_conv_forward(d) would make (the kernel selection and its grid are decided exactly as in
+ * the real call, nothing is launched); < 0 on error.  Size `stats` with it and pass it as stats_slots. */
+int ieagan_conv_stats_slots(const ieagan_conv_desc* d);
 
 /* ---- weight gradient: dWp[Cout][Kpad] += G^T A   (autograd of F.conv2d w.r.t. weight) -------- */
 typedef struct {
@@ -135,11 +143,12 @@ typedef struct {
     int lC, lCa, lmode;
     void* dx;                 /* bf16, see out_mode; NULL: no data gradient                                          */
     int out_mode;
-    float* bn_acc;            /* fp32 [N][8][2][Cin], caller-zeroed (affine prologue)                                */
+    float* bn_acc;            /* fp32 [N][bn_slots][2][Cin], caller-zeroed (affine prologue)                         */
     float* dw;                /* fp32 [Cout][Kpad], accumulated; NULL: no weight gradient                            */
     float* partials;          /* optional workspace of ieagan_conv1x1_bwd_workspace(d) floats (two-stage accumulation) */
     float* colsum;            /* optional fp32 [32][Cout] caller-zeroed replicas (bias gradient)                     */
     int flags;                /* IEAGAN_B1_* (benchmarks: force the 2 / 3 blocks-per-CU build of the kernel)         */
+    int bn_slots;             /* bn_acc is [N][bn_slots][2][Cin]; == ieagan_conv1x1_bwd_slots(d): one adder per slot (bit-reproducible); 0: 8 */
 } ieagan_conv1x1_bwd_desc;
 #define IEAGAN_B1_OCC2 1
 #define IEAGAN_B1_OCC3 2
@@ -147,6 +156,40 @@ typedef struct {
 int ieagan_conv1x1_bwd(const ieagan_conv1x1_bwd_desc* d, void* stream);
 long ieagan_conv1x1_bwd_workspace(const ieagan_conv1x1_bwd_desc* d);
 int ieagan_conv1x1_bwd_supported(int Cin, int Cout, int rs, int affine);
+int ieagan_conv1x1_bwd_slots(const ieagan_conv1x1_bwd_desc* d);      /* blocks per image of the launch */
+
+/* ---- the whole backward of a 3x3 convolution with Cin = Cout = C in {16, 32} on a large feature map in one launch (conv3x3_bwd.hip) ----
+ * Replaces, per layer and backward pass, ieagan_effgrad -> ieagan_conv_forward (as dgrad) [-> ieagan_prologue_bwd] -> ieagan_conv_wgrad, i.e.
+ * autograd of  F.conv2d(relu(bn(x)) | relu(x) | F.interpolate(relu(bn(x)), 2), W / sigma, b, padding=1)  (reference layers.py:197-206,
+ * 656-689; model.py:54-71 GBlock conv2 / conv3, 541-557 DBlock conv2 / conv3): g (and y) are read once with a one-pixel halo, x once.
+ *   g_eff = g + dsum[e][c] + 2 y dsumsq[e][c]   inside the image, 0 outside   (y / dstat NULL: g_eff = g)
+ *   da[q] = sum_tap g_eff[q - off(tap)] W[.][tap, .]                            w_bwd = the flipped / transposed pack [C][Kpad]
+ *   dx[N,Hs,Ws,C] = prologue'(x) (.) resample^T(da): ReLU mask; with the affine prologue dx = d * scale[n,c] and
+ *                   bn_acc[N][8][2][C] += {sum d, sum d*x} per image (as ieagan_conv_desc.bnb_*); rs = 1: 2x2 sum of da first
+ *   dw[C][Kpad] += sum_q g_eff[q - off(tap)]^T a[q]  (a = the forward's activated, resampled input);  colsum[32][C] += column sums of g_eff
+ * The prologue must include the ReLU (every 3x3 layer of the path does).  H % 8 == 0, W % 32 == 0 (conv resolution). */
+typedef struct {
+    int N, H, W;              /* conv (output) resolution                                                            */
+    int C, Kpad;              /* Cin = Cout = C; Kpad = pad32(9 C), the row length of both weight packs               */
+    ieagan_src_desc src;      /* the forward's source operand with its prologue (rs 0 or 1, relu = 1)                */
+    const void* g;            /* bf16 out-grad, channels [0,C) of Cg                                                 */
+    int Cg;
+    const void* y;            /* bf16 [N,H,W,C] forward output (effgrad) or NULL                                     */
+    const float* dstat;       /* fp32 [E][2][C] (dsum, dsumsq) or NULL                                               */
+    int n_per_event;          /* images per event (0: one event)                                                     */
+    const void* w_bwd;        /* bf16 [C][Kpad]                                                                      */
+    void* dx;                 /* bf16 [N,Hs,Ws,C]                                                                    */
+    float* bn_acc;            /* fp32 [N][bn_slots][2][C], caller-zeroed (affine prologue), else NULL                */
+    float* dw;                /* fp32 [C][Kpad], accumulated                                                         */
+    float* partials;          /* workspace of ieagan_conv3x3_bwd_workspace(d) floats: one dW slab per block          */
+    float* colsum;            /* optional fp32 [32][C] caller-zeroed replicas (bias gradient)                        */
+    int flags;                /* 0                                                                                   */
+    int bn_slots;             /* bn_acc is [N][bn_slots][2][C]; == ieagan_conv3x3_bwd_slots(d): one adder per slot (bit-reproducible); 0: 8 */
+} ieagan_conv3x3_bwd_desc;
+int ieagan_conv3x3_bwd(const ieagan_conv3x3_bwd_desc* d, void* stream);
+long ieagan_conv3x3_bwd_workspace(const ieagan_conv3x3_bwd_desc* d);
+int ieagan_conv3x3_bwd_supported(int C, int rs, int affine, int relu, int effgrad, int H, int W);
+int ieagan_conv3x3_bwd_slots(const ieagan_conv3x3_bwd_desc* d);      /* blocks per image of the launch */
 
 /* ---- element-wise companions (bn_elem.hip) ---------------------------------------------------- */
 /* g_eff = dout + dsum[e][c] + 2*out*dsumsq[e][c]; colsum[32][C] += column sums (bias gradient).
@@ -161,21 +204,22 @@ int ieagan_prologue_bwd(const void* da, const void* x, int Cx, const float* scal
                         int nstride, int relu, int rs, void* dx, float* dscale, float* dshift,
                         int N, int Hs, int Ws, int C, const void* radd, int Cr, int Ca, int rmode, void* stream);
 /* ccbn / bn statistics -> scale/shift (+ running-stat update), layers.py:656-689, 728-742.
- * E events of N / E images: stats [E][32][2][C] (count = elements per channel of ONE event), mean_rstd [E][2][C],
+ * E events of N / E images: stats [E][repl][2][C] (count = elements per channel of ONE event; the slots are folded in a fixed order), mean_rstd [E][2][C],
  * dstat [E][2][C]; the running statistics receive the mean of the E per-event momentum updates.  ld == 0 (plain bn):
  * per-channel gain / bias; scale / shift then have rows = 1 for E == 1 and rows = N (one per image) for E > 1, and
  * dgain / dbias are summed over the rows. */
 int ieagan_bn_finalize_fwd(const float* stats, float count, const float* gain, const float* bias, int ld,
                            int plus_one, float eps, float momentum, int training, float* run_mean,
                            float* run_var, float* scale, float* shift, float* mean_rstd, int N, int C, int E,
-                           void* stream);
+                           int repl, void* stream);
 /* acc_repl > 0: dshift is ignored and dscale points at the replicated per-image accumulators [rows][acc_repl][2][C]
  * ({sum d, sum d*x}) a BatchNorm-backward dgrad launch produced (ieagan_conv_desc.bnb_*); they are folded here. */
 int ieagan_bn_finalize_bwd(const float* dscale, const float* dshift, const float* gain, int ld, int plus_one,
                            const float* mean_rstd, float count, int training, float* dgain, float* dbias,
                            int ldd, float* dstat, int N, int C, int E, int acc_repl, void* stream);
 int ieagan_res_bwd(const void* g, int Cg, void* dr, int Cr, int Ca, int mode, int N, int Hr, int Wr, void* stream);
-/* stats (optional): fp32 [E][32][2][C] per-event replicated (sum, sumsq), E = N / n_per_event (0: one event) */
+/* stats (optional): fp32 [E][S][2][C] caller-zeroed (sum, sumsq) slots per event, E = N / n_per_event (0: one event),
+ * S = (N / E) * ceil(HW / 32): one slot per (image of the event, 32-pixel block) -- a single adder each, bit-reproducible */
 int ieagan_nchw_to_nhwc(const float* in, void* out, float* stats, int N, int C, int HW, int n_per_event, void* stream);
 int ieagan_nhwc_to_nchw(const void* in, float* out, int N, int C, int HW, void* stream);
 int ieagan_channel_stats(const void* x, float* stats, long P, int C, void* stream);
