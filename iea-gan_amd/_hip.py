@@ -18,6 +18,8 @@ CONV_FP8 = 4             # ieagan_conv_desc.flags bit: e4m3 MFMA operands in the
 CONV_NO_LDS_WEIGHTS = 2  # ieagan_conv_desc.flags bit: C = 64 / 128 3x3 layers through conv3x3_halo instead of conv3x3_lds
 CONV_FORCE_GATHER = 1   # ieagan_conv_desc.flags bit (tests): route a 3x3 layer through the gather kernel
 B1_OCC2, B1_OCC3, B1_TP32 = 1, 2, 4  # ieagan_conv1x1_bwd_desc.flags bits (benchmarks)
+PROLOGUE_BWD_SLOTS = 64  # include/ieagan_hip.h: IEAGAN_PROLOGUE_BWD_SLOTS
+AUG_SLOTS = 128         # include/ieagan_hip.h: IEAGAN_AUG_SLOTS (per-image partial-sum slots of the DiffAugment entry points)
 BNB_REPL = 8            # replicas of the per-image accumulators of a BatchNorm-backward dgrad launch (common.h)
 STAT_REPL = 32          # replicas of every (sum, sumsq) statistics buffer (common.h)
 SN_FIELDS = 16          # int64 fields per row of the spectral-norm layer table (sn.hip)
@@ -90,7 +92,7 @@ _SIGS = {
     "ieagan_d_stem_fwd": [C.POINTER(DStemDesc), vp],
     "ieagan_d_stem_bwd": [C.POINTER(DStemDesc), vp],
     "ieagan_effgrad": [vp, vp, vp, vp, vp, l, i, i, vp],
-    "ieagan_prologue_bwd": [vp, vp, i, vp, vp, i, i, i, vp, vp, vp, i, i, i, i, vp, i, i, i, vp],
+    "ieagan_prologue_bwd": [vp, vp, i, vp, vp, i, i, i, vp, vp, vp, i, i, i, i, vp, i, i, i, i, vp],
     "ieagan_bn_finalize_fwd": [vp, f, vp, vp, i, i, f, f, i, vp, vp, vp, vp, vp, i, i, i, i, vp],
     "ieagan_bn_finalize_bwd": [vp, vp, vp, i, i, vp, f, i, vp, vp, i, vp, i, i, i, i, vp],
     "ieagan_res_bwd": [vp, i, vp, i, i, i, i, i, i, vp],
@@ -98,7 +100,8 @@ _SIGS = {
     "ieagan_nhwc_to_nchw": [vp, vp, i, i, i, vp],
     "ieagan_channel_stats": [vp, vp, l, i, vp],
     "ieagan_conv_1toC": [vp, vp, vp, vp, vp, i, i, i, i, i, vp],
-    "ieagan_conv_1toC_bnb": [vp, vp, vp, vp, vp, vp, i, i, vp, vp, vp, i, i, i, i, i, vp],
+    "ieagan_conv_1toC_bnb": [vp, vp, vp, vp, vp, vp, i, i, vp, vp, vp, i, i, i, i, i, i, vp],
+    "ieagan_conv_1toC_bnb_slots": [i, i, i, i],
     "ieagan_conv_Cto1": [vp, vp, vp, i, i, vp, vp, vp, i, i, i, i, i, i, vp],
     "ieagan_wgrad_c1": [vp, vp, vp, vp, vp, i, i, vp, i, i, i, i, i, vp],
     "ieagan_sn_backward_batched": [vp, vp, i, vp, vp, vp, vp, vp],

@@ -5,7 +5,9 @@
 //   EMA over the whole flat state                               (utils/__init__.py:825-837)
 #include "common.h"
 
-// per-image sums: out[n] += sum_hw f(x)
+// per-image sums in AUG_SLOTS slots per image: block b of image n STORES its partial into out[n][b] (one writer per slot; the grid never
+// has more than AUG_SLOTS blocks per image), the consumers fold the slots in a fixed order (aug_fold) -- bit-reproducible, unlike one
+// float atomic per block on out[n]
 //   MODE 0: f = x                                   (mean for rand_contrast)
 //   MODE 1: f = gout at positions that survive translation + cutout (mean term of the backward)
 struct AugDraws {
@@ -33,6 +35,7 @@ __device__ __forceinline__ bool in_cut(int h, int w, int H, int W, int ox, int o
 // for a 31 MB image batch, 0.5 TB/s).  Source indices are clamped (unconditional loads), validity is a select.
 typedef float af4 __attribute__((ext_vector_type(4)));
 
+#define AUG_SLOTS 128          // partial-sum slots per image (== the largest row grid); include/ieagan_hip.h: IEAGAN_AUG_SLOTS
 template <int MODE>
 __global__ __launch_bounds__(256) void aug_sum_kernel(const float* __restrict__ x, AugDraws d, float* __restrict__ out, int H, int W) {
     __shared__ float red[4];
@@ -69,7 +72,14 @@ __global__ __launch_bounds__(256) void aug_sum_kernel(const float* __restrict__ 
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out + n, red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) out[(long)n * AUG_SLOTS + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// sum of the AUG_SLOTS slots of image n, by every thread in the same fixed order (unused slots hold the caller's zeros)
+__device__ __forceinline__ float aug_fold(const float* __restrict__ sums, int n) {
+    float s = 0.f;
+    for (int k = 0; k < AUG_SLOTS; ++k) s += sums[(long)n * AUG_SLOTS + k];
+    return s;
 }
 
 __global__ __launch_bounds__(256) void diffaug_fwd_kernel(const float* __restrict__ x, AugDraws d, const float* __restrict__ sums,
@@ -77,7 +87,7 @@ __global__ __launch_bounds__(256) void diffaug_fwd_kernel(const float* __restric
     const int n = blockIdx.y;
     const long HW = (long)H * W;
     const float b = d.bright[n] - 0.5f, c = d.contrast[n] + 0.5f;
-    const float m = sums[n] / (float)HW + b;          // mean of the brightened image
+    const float m = aug_fold(sums, n) / (float)HW + b;          // mean of the brightened image
     const int tx = (int)d.tx[n], ty = (int)d.ty[n], ox = (int)d.ox[n], oy = (int)d.oy[n];
     const float* xi = x + (long)n * HW;
     float* oi = out + (long)n * HW;
@@ -113,7 +123,7 @@ __global__ __launch_bounds__(256) void diffaug_bwd_kernel(const float* __restric
     const int n = blockIdx.y;
     const long HW = (long)H * W;
     const float c = d.contrast[n] + 0.5f;
-    const float mterm = (1.f - c) * gsums[n] / (float)HW;
+    const float mterm = (1.f - c) * aug_fold(gsums, n) / (float)HW;
     const int tx = (int)d.tx[n], ty = (int)d.ty[n], ox = (int)d.ox[n], oy = (int)d.oy[n];
     const float* gi = gout + (long)n * HW;
     float* oi = gx + (long)n * HW;
@@ -149,12 +159,12 @@ static inline dim3 img_grid(int N, long HW) {
     return dim3((unsigned)b, N);
 }
 static inline dim3 row_grid(int N, int H) {        // the row-based kernels: one block per 1..4 rows of an image
-    int b = H < 128 ? H : 128;
+    int b = H < AUG_SLOTS ? H : AUG_SLOTS;
     return dim3((unsigned)b, N);
 }
 
 extern "C" int ieagan_diffaug_fwd(const float* x, const float* bright, const float* contrast, const long* tx, const long* ty,
-                                  const long* ox, const long* oy, float* sums /*[N] zeroed*/, float* out, int N, int H, int W,
+                                  const long* ox, const long* oy, float* sums /*[N][128] zeroed*/, float* out, int N, int H, int W,
                                   void* stream) {
     hipStream_t st = (hipStream_t)stream;
     AugDraws d{bright, contrast, tx, ty, ox, oy};
@@ -166,7 +176,7 @@ extern "C" int ieagan_diffaug_fwd(const float* x, const float* bright, const flo
 }
 
 extern "C" int ieagan_diffaug_bwd(const float* gout, const float* contrast, const long* tx, const long* ty, const long* ox,
-                                  const long* oy, float* gsums /*[N] zeroed*/, float* gx, int N, int H, int W, void* stream) {
+                                  const long* oy, float* gsums /*[N][128] zeroed*/, float* gx, int N, int H, int W, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     AugDraws d{nullptr, contrast, tx, ty, ox, oy};
     ProfScope prof("diffaug_bwd", 0.0, 12.0 * N * H * W, st);

@@ -10,6 +10,7 @@
 // Replaces F.batch_norm / ccbn / relu / interpolate / AvgPool2d backward of the reference
 // (layers.py:656-689, 728-742; model.py:54-71, 541-557).
 #include "common.h"
+#include "../../include/ieagan_hip.h"
 
 // ------------------------------------------------------------------------------------------------
 // block-level reduction of 8 per-thread partials by channel group; thread t owns channel group
@@ -19,6 +20,7 @@
 // channel group stays fixed over a grid-stride loop for ANY channel count that is a multiple of 8.
 __device__ __forceinline__ int active_threads(int groups) { return (256 / groups) * groups; }
 
+template <bool STORE = false>
 __device__ __forceinline__ void reduce_groups_atomic(float (&part)[8], int groups, float* dst, float* red /*[256][8]*/) {
     const int t = threadIdx.x;
     const int active = active_threads(groups);
@@ -29,7 +31,8 @@ __device__ __forceinline__ void reduce_groups_atomic(float (&part)[8], int group
         const int g = o >> 3, i = o & 7;
         float s = 0.f;
         for (int u = g; u < active; u += groups) s += red[u * 8 + i];
-        atomicAdd(dst + g * 8 + i, s);
+        if (STORE) dst[g * 8 + i] = s;          // the block owns dst (its slot): plain store, bit-reproducible
+        else atomicAdd(dst + g * 8 + i, s);
     }
     __syncthreads();
 }
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(256) void prologue_bwd_kernel(const bf16* __restric
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            int nstride, bf16* __restrict__ dx, float* __restrict__ dscale,
                                                            float* __restrict__ dshift, int Hs, int Ws, int C,
-                                                           const bf16* __restrict__ radd, int Cr, int Ca, int rmode) {
+                                                           const bf16* __restrict__ radd, int Cr, int Ca, int rmode, int slots) {
     __shared__ float red[256 * 8];
     const int n = blockIdx.y;
     const int groups = C >> 3;
@@ -181,29 +184,36 @@ __global__ __launch_bounds__(256) void prologue_bwd_kernel(const bf16* __restric
         *(bf16x8*)(dx + (((long)n * Hs + hs) * Ws + ws) * C + cg * 8) = o;
     }
     if (AFF) {
-        reduce_groups_atomic(p_ds, groups, dscale + (long)n * nstride, red);
-        reduce_groups_atomic(p_dt, groups, dshift + (long)n * nstride, red);
+        if (slots > 0) {        // dscale = acc [N][slots][2][C]: this block's own slot {sum d, sum d x} (the layout of the dgrad epilogue's accumulators)
+            float* slot = dscale + (((long)n * slots + blockIdx.x) * 2) * C;
+            reduce_groups_atomic<true>(p_dt, groups, slot, red);
+            reduce_groups_atomic<true>(p_ds, groups, slot + C, red);
+        } else {
+            reduce_groups_atomic(p_ds, groups, dscale + (long)n * nstride, red);
+            reduce_groups_atomic(p_dt, groups, dshift + (long)n * nstride, red);
+        }
     }
 }
 
 extern "C" int ieagan_prologue_bwd(const void* da, const void* x, int Cx, const float* scale, const float* shift,
                                    int nstride, int relu, int rs, void* dx, float* dscale, float* dshift, int N, int Hs,
-                                   int Ws, int C, const void* radd, int Cr, int Ca, int rmode, void* stream) {
+                                   int Ws, int C, const void* radd, int Cr, int Ca, int rmode, int slots, void* stream) {
     CHECK_ARG(radd == nullptr || (Ca % 8 == 0 && Ca <= C && Ca <= Cr && (rmode == 0 || rmode == 1)), "prologue_bwd: bad shortcut-gradient operand");
     CHECK_ARG(C % 8 == 0 && C <= 2048, "prologue_bwd: C=%d unsupported", C);
     CHECK_ARG(rs >= 0 && rs <= 2, "prologue_bwd: bad rs");
     CHECK_ARG(rs != 2 || (Hs % 2 == 0 && Ws % 2 == 0), "prologue_bwd: pooled source needs even size");
-    CHECK_ARG(scale == nullptr || (shift && dscale && dshift), "prologue_bwd: affine needs shift/dscale/dshift");
+    CHECK_ARG(scale == nullptr || (shift && dscale && (dshift || slots > 0)), "prologue_bwd: affine needs shift/dscale/dshift");
+    CHECK_ARG(slots == 0 || slots >= IEAGAN_PROLOGUE_BWD_SLOTS, "prologue_bwd: slots must be 0 or >= %d", IEAGAN_PROLOGUE_BWD_SLOTS);
     hipStream_t st = (hipStream_t)stream;
     const double px = (double)N * Hs * Ws * C;
     ProfScope prof("prologue_bwd", 0.0, 2.0 * px * (rs == 1 ? 6.0 : rs == 2 ? 2.25 : 3.0), st);
     long per = ((long)Hs * Ws * (C / 8) + 255) / 256;
-    if (per > 64) per = 64;
+    if (per > IEAGAN_PROLOGUE_BWD_SLOTS) per = IEAGAN_PROLOGUE_BWD_SLOTS;
     if (per < 1) per = 1;
     dim3 grid((unsigned)per, N);
     const bool aff = scale != nullptr;
 #define PB(A, R, S) hipLaunchKernelGGL((prologue_bwd_kernel<A, R, S>), grid, dim3(256), 0, st, (const bf16*)da, (const bf16*)x, Cx, \
-                                       scale, shift, nstride, (bf16*)dx, dscale, dshift, Hs, Ws, C, (const bf16*)radd, Cr, Ca, rmode)
+                                       scale, shift, nstride, (bf16*)dx, dscale, dshift, Hs, Ws, C, (const bf16*)radd, Cr, Ca, rmode, slots)
 #define PB_RS(A, R)            \
     if (rs == 0) PB(A, R, 0);  \
     else if (rs == 1) PB(A, R, 1); \

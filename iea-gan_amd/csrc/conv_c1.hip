@@ -26,6 +26,9 @@ struct C1Bnb {
     int nstride, relu;
     float* dscale;            // accumulated (atomics), rows n * nstride
     float* dshift;
+    // slots > 0: dscale = acc [rows][slots][2][C] ({sum d, sum d x}; rows = N, or 1 when nstride == 0), caller-zeroed; a block adds into slot
+    // (its index - first block of the image) of the image's row -- one adder per address, bit-reproducible sums; dshift unused
+    int slots, tiles_img;
 };
 template <int C, bool BNB = false>
 __global__ __launch_bounds__(256) void conv_1toC_kernel(const float* __restrict__ img, const float* __restrict__ tanh_y,
@@ -77,7 +80,14 @@ __global__ __launch_bounds__(256) void conv_1toC_kernel(const float* __restrict_
                 const int g = o2 >> 3, i = o2 & 7;
                 float sacc = 0.f;
                 for (int u = g; u < 256; u += G) sacc += bred[u * 8 + i];
-                atomicAdd((w2 ? bnb.dshift : bnb.dscale) + (long)n_row * bnb.nstride + o2, sacc);
+                if (bnb.slots > 0) {
+                    const int per_ = (gridDim.x + N * bnb.tiles_img - 1) / gridDim.x;               // tiles per block (== `per` below)
+                    const long row = bnb.nstride != 0 ? n_row : 0;
+                    const int slot = bnb.nstride != 0 ? (int)blockIdx.x - (int)(((long)n_row * bnb.tiles_img) / per_) : (int)blockIdx.x;
+                    atomicAdd(bnb.dscale + ((row * bnb.slots + slot) * 2 + (w2 ? 0 : 1)) * C + o2, sacc);
+                } else {
+                    atomicAdd((w2 ? bnb.dshift : bnb.dscale) + (long)n_row * bnb.nstride + o2, sacc);
+                }
             }
         }
 #pragma unroll
@@ -182,17 +192,41 @@ __global__ __launch_bounds__(256) void conv_1toC_kernel(const float* __restrict_
 
 // conv_1toC with the BatchNorm-apply + ReLU backward folded into its store phase (see C1Bnb): the dgrad of G.output_layer
 // (model.py:379-387).  dx [N,H,W,C] bf16; dscale / dshift fp32, caller-zeroed, rows n * nstride (nstride 0: one row for the batch).
+// grid of the launch: blocks, tiles per image, slots per accumulator row (see C1Bnb)
+static void c1_bnb_plan(int N, int H, int W, int nstride, long& blocks, int& tiles_img, int& slots) {
+    const int tiles_w = (W + I1_TW - 1) / I1_TW, tiles_h = (H + I1_TH - 1) / I1_TH;
+    tiles_img = tiles_w * tiles_h;
+    const long ntl = (long)N * tiles_img;
+    blocks = ntl < 2048 ? ntl : 2048;
+    if (blocks < 1) blocks = 1;
+    const long per = (ntl + blocks - 1) / blocks;
+    slots = nstride != 0 ? (int)((tiles_img + per - 1) / per) + 1 : (int)blocks;
+}
+
+extern "C" int ieagan_conv_1toC_bnb_slots(int N, int H, int W, int nstride) {
+    long blocks;
+    int tiles_img, slots;
+    c1_bnb_plan(N, H, W, nstride, blocks, tiles_img, slots);
+    return slots;
+}
+
 extern "C" int ieagan_conv_1toC_bnb(const float* img, const float* tanh_y, const float* w, const void* x, const float* scale,
                                     const float* shift, int nstride, int relu, void* dx, float* dscale, float* dshift, int N, int H,
-                                    int W, int C, int flip, void* stream) {
+                                    int W, int C, int flip, int slots, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    CHECK_ARG(x && scale && shift && dx && dscale && dshift, "conv_1toC_bnb: null operand");
+    CHECK_ARG(x && scale && shift && dx && dscale && (dshift || slots > 0), "conv_1toC_bnb: null operand");
+    {
+        long pb;
+        int pt, ps;
+        c1_bnb_plan(N, H, W, nstride, pb, pt, ps);
+        CHECK_ARG(slots == 0 || slots >= ps, "conv_1toC_bnb: %d slots, the launch needs %d (ieagan_conv_1toC_bnb_slots)", slots, ps);
+    }
     ProfScope prof("conv_1toC", 18.0 * N * H * W * (double)C, (double)N * H * W * (4.0 + 4.0 * C), st);
     const int tiles_w = (W + I1_TW - 1) / I1_TW, tiles_h = (H + I1_TH - 1) / I1_TH;
     const long ntl = (long)N * tiles_w * tiles_h;
     CHECK_ARG(ntl > 0 && ntl < (1L << 31), "conv_1toC_bnb: bad geometry");
     const long blocks = ntl < 2048 ? ntl : 2048;
-    C1Bnb b{(const bf16*)x, scale, shift, nstride, relu, dscale, dshift};
+    C1Bnb b{(const bf16*)x, scale, shift, nstride, relu, dscale, dshift, slots, tiles_w * tiles_h};
 #define L(CC) hipLaunchKernelGGL((conv_1toC_kernel<CC, true>), dim3((unsigned)blocks), dim3(256), 0, st, img, tanh_y, w, (const float*)nullptr, (bf16*)dx, N, H, W, flip, tiles_w, tiles_h, b)
     if (C == 16) L(16);
     else if (C == 32) L(32);

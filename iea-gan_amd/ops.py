@@ -970,17 +970,26 @@ class ConvFn(torch.autograd.Function):
                     dx = da
                 else:
                     dx = torch.empty(N, Hs, Ws, Cin, dtype=BF16, device=dev)
-                    if has_aff:
-                        dscale = zeros(scale.shape, dev)
-                        dshift = zeros(shift.shape, dev)
+                    acc = None
+                    if has_aff:     # per-image {sum d, sum d x} in one slot per block (single writer: bit-reproducible), folded by bn_finalize_bwd
+                        acc = zeros((N, H.PROLOGUE_BWD_SLOTS, 2, Cin), dev)
                     rmode = 0
                     if res_in is not None:
                         if lmode == 2:
                             raise RuntimeError("pooled shortcut gradient cannot be added by prologue_bwd")
                         rmode = lmode
                     H.call("ieagan_prologue_bwd", da.data_ptr(), x.data_ptr(), Cx, H.ptr(scale), H.ptr(shift), nstride, int(relu),
-                           rs, dx.data_ptr(), H.ptr(dscale), H.ptr(dshift), N, Hs, Ws, Cin, H.ptr(lg), lC or 0, lCa or 0, rmode,
-                           H.stream())
+                           rs, dx.data_ptr(), H.ptr(acc), None, N, Hs, Ws, Cin, H.ptr(lg), lC or 0, lCa or 0, rmode,
+                           H.PROLOGUE_BWD_SLOTS if has_aff else 0, H.stream())
+                    if has_aff:
+                        if bn_link is not None:
+                            bn_link.acc = acc
+                            dscale = dshift = _placeholder(scale)
+                        else:                       # stand-alone use (tests): fold the per-image slots here
+                            sums = acc.sum(1)
+                            dshift, dscale = sums[:, 0], sums[:, 1]
+                            if nstride == 0:
+                                dshift, dscale = dshift.sum(0), dscale.sum(0)
             if fan_in is not None:
                 if not (plain and rs == 0 and dx is da):
                     raise RuntimeError("a fan-in gradient link needs a plain same-resolution conv")
@@ -1181,9 +1190,13 @@ class OutputConvFn(torch.autograd.Function):
             # tensor (0.5 GB at 256x768) is never written (was: conv_1toC -> da, then prologue_bwd over da and h)
             dh = torch.empty_like(h)
             ns = 0 if scale.dim() == 1 else C
-            dscale, dshift = zeros(scale.shape, dev), zeros(shift.shape, dev)
+            # {sum d, sum d x} in single-adder slots (bit-reproducible), folded here in a fixed order
+            slots = H.lib().ieagan_conv_1toC_bnb_slots(N, Hh, Ww, ns)
+            acc = zeros((N if ns else 1, slots, 2, C), dev)
             H.call("ieagan_conv_1toC_bnb", dpre.data_ptr(), None, rec.w_plain.data_ptr(), h.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                   ns, 1, dh.data_ptr(), dscale.data_ptr(), dshift.data_ptr(), N, Hh, Ww, C, 1, H.stream())
+                   ns, 1, dh.data_ptr(), acc.data_ptr(), None, N, Hh, Ww, C, 1, slots, H.stream())
+            sums = acc.sum(1)
+            dshift, dscale = sums[:, 0].reshape(shift.shape), sums[:, 1].reshape(scale.shape)
         if need[3]:
             dw = sn_scratch(rec, "w", (9, C), dev)
             H.call("ieagan_wgrad_c1", dpre.data_ptr(), None, h.data_ptr(), scale.data_ptr(), shift.data_ptr(),
@@ -1624,7 +1637,7 @@ class DiffAugFn(torch.autograd.Function):
         N, C, Hh, Ww = x.shape
         x = x.contiguous()
         out = torch.empty_like(x)
-        sums = zeros((N,), x.device)
+        sums = zeros((N, H.AUG_SLOTS), x.device)
         H.call("ieagan_diffaug_fwd", x.data_ptr(), bright.data_ptr(), contrast.data_ptr(), tx.data_ptr(), ty.data_ptr(),
                ox.data_ptr(), oy.data_ptr(), sums.data_ptr(), out.data_ptr(), N, Hh, Ww, H.stream())
         ctx.save_for_backward(contrast, tx, ty, ox, oy)
@@ -1636,7 +1649,7 @@ class DiffAugFn(torch.autograd.Function):
         N, C, Hh, Ww = g.shape
         g = g.contiguous()
         gx = torch.empty_like(g)
-        gs = zeros((N,), g.device)
+        gs = zeros((N, H.AUG_SLOTS), g.device)
         H.call("ieagan_diffaug_bwd", g.data_ptr(), contrast.data_ptr(), tx.data_ptr(), ty.data_ptr(), ox.data_ptr(),
                oy.data_ptr(), gs.data_ptr(), gx.data_ptr(), N, Hh, Ww, H.stream())
         return gx, None, None, None, None, None, None

@@ -197,12 +197,16 @@ int ieagan_conv3x3_bwd_slots(const ieagan_conv3x3_bwd_desc* d);      /* blocks p
  * consecutive pixels each, dstat fp32 [E][2][C]. */
 int ieagan_effgrad(const void* dout, const void* out, const float* dstat, void* geff, float* colsum,
                    long P, int C, int E, void* stream);
-/* backward of the fused prologue: dx, and per-(n,c) d scale / d shift (atomically accumulated).
+/* backward of the fused prologue: dx, and per-(n,c) d scale / d shift.
  * radd (optional): gradient of a shortcut that read the same x (channels [0,Ca) of a tensor with Cr
- * channels; rmode 0 same resolution, 1 = 2x2 sum of a tensor at double resolution), added into dx. */
+ * channels; rmode 0 same resolution, 1 = 2x2 sum of a tensor at double resolution), added into dx.
+ * slots == 0: dscale / dshift fp32 rows n * nstride, caller-zeroed, accumulated with float atomics (order-dependent last bits);
+ * slots >= IEAGAN_PROLOGUE_BWD_SLOTS: dscale points at per-image accumulators fp32 [N][slots][2][C] ({sum d, sum d*x}, caller-zeroed; the
+ * layout ieagan_bn_finalize_bwd takes with acc_repl = slots), every block stores into its own slot: bit-reproducible; dshift unused. */
+#define IEAGAN_PROLOGUE_BWD_SLOTS 64
 int ieagan_prologue_bwd(const void* da, const void* x, int Cx, const float* scale, const float* shift,
                         int nstride, int relu, int rs, void* dx, float* dscale, float* dshift,
-                        int N, int Hs, int Ws, int C, const void* radd, int Cr, int Ca, int rmode, void* stream);
+                        int N, int Hs, int Ws, int C, const void* radd, int Cr, int Ca, int rmode, int slots, void* stream);
 /* ccbn / bn statistics -> scale/shift (+ running-stat update), layers.py:656-689, 728-742.
  * E events of N / E images: stats [E][repl][2][C] (count = elements per channel of ONE event; the slots are folded in a fixed order), mean_rstd [E][2][C],
  * dstat [E][2][C]; the running statistics receive the mean of the E per-event momentum updates.  ld == 0 (plain bn):
@@ -230,9 +234,13 @@ int ieagan_conv_1toC(const float* img, const float* tanh_y, const float* w, cons
                      int N, int H, int W, int C, int flip, void* stream);
 /* the same as a dgrad with the BatchNorm-apply + ReLU backward of G.output_layer's prologue folded into the store phase (model.py:379-387):
  * dx[n,h,w,c] = d * scale[n*nstride + c], d = (relu && !(x*scale+shift > 0)) ? 0 : conv;  dshift += sum d, dscale += sum d * x (caller-zeroed,
- * rows n * nstride; nstride 0: one row for the batch).  The gradient w.r.t. the activated tensor is never materialised. */
+ * rows n * nstride; nstride 0: one row for the batch).  The gradient w.r.t. the activated tensor is never materialised.
+ * slots >= ieagan_conv_1toC_bnb_slots(N, H, W, nstride): dscale points at accumulators fp32 [rows][slots][2][C] ({sum d, sum d*x}; rows = N,
+ * or 1 with nstride 0; caller-zeroed) with ONE adder per address (bit-reproducible sums); dshift unused.  slots 0: float atomics on the rows. */
 int ieagan_conv_1toC_bnb(const float* img, const float* tanh_y, const float* w, const void* x, const float* scale, const float* shift,
-                         int nstride, int relu, void* dx, float* dscale, float* dshift, int N, int H, int W, int C, int flip, void* stream);
+                         int nstride, int relu, void* dx, float* dscale, float* dshift, int N, int H, int W, int C, int flip, int slots,
+                         void* stream);
+int ieagan_conv_1toC_bnb_slots(int N, int H, int W, int nstride);
 /* tanh_out: 0 = linear, 1 = tanh, 2 = tanh + the detector-unit export of model.generate (model.py:1139-1147:
  * threshold(-0.26 -> -1), 256^((r+1)/2) - 1, clamp to [0, 255], rows 3 .. H-4 only): out is then fp32 [N, H-6, W]. */
 int ieagan_conv_Cto1(const void* x, const float* scale, const float* shift, int nstride, int relu,
@@ -348,6 +356,8 @@ int ieagan_gamma_residual_bwd(const void* d, const void* o, const float* gamma, 
                               void* stream);
 
 /* ---- augmentation + optimiser (aug_optim.hip) -------------------------------------------------- */
+#define IEAGAN_AUG_SLOTS 128      /* sums / gsums of the two DiffAugment entry points: fp32 [N][IEAGAN_AUG_SLOTS], caller-zeroed (per-image partial
+                                   * sums, one writer per slot, folded in a fixed order: bit-reproducible image means) */
 int ieagan_diffaug_fwd(const float* x, const float* bright, const float* contrast, const long* tx, const long* ty,
                        const long* ox, const long* oy, float* sums, float* out, int N, int H, int W, void* stream);
 int ieagan_diffaug_bwd(const float* gout, const float* contrast, const long* tx, const long* ty, const long* ox,

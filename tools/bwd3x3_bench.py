@@ -56,9 +56,12 @@ for name, C, Hc, Wc, rs, aff, eff in CASES:
     moved = 2.0 * (P * C * (1 + eff) + 2 * Ps * C)
     d = H.Conv3x3BwdDesc(N, Hc, Wc, C, kpad, H.src_desc(x, C, Hs, Ws, rs, sc, sh, C if aff else 0, True), g.data_ptr(), C, H.ptr(y), H.ptr(dstat), N,
                          wb.data_ptr(), dx.data_ptr(), H.ptr(acc), dw.data_ptr(), None, cs.data_ptr(), 0)
-    ws = torch.empty(H.lib().ieagan_conv3x3_bwd_workspace(d), device=dev)
-    d.partials = ws.data_ptr()
-    us = timed(lambda: H.call("ieagan_conv3x3_bwd", d, H.stream()))
+    fused_ok = H.lib().ieagan_conv3x3_bwd_supported(C, rs, aff, 1, eff, Hc, Wc)
+    us = float("nan")
+    if fused_ok:
+        ws = torch.empty(H.lib().ieagan_conv3x3_bwd_workspace(d), device=dev)
+        d.partials = ws.data_ptr()
+        us = timed(lambda: H.call("ieagan_conv3x3_bwd", d, H.stream()))
     # ---- the separate launches
     geff = torch.empty_like(g)
     da = torch.empty(N, Hc, Wc, C, device=dev, dtype=BF)
@@ -84,7 +87,7 @@ for name, C, Hc, Wc, rs, aff, eff in CASES:
         else:
             ops._conv_launch(gg, C, Hc, Wc, 0, None, None, 0, False, N, Hc, Wc, C, C, 9, kpad, wb, None, None, 0, 0, 0, None, 0, None, da, None)
             H.call("ieagan_prologue_bwd", da.data_ptr(), x.data_ptr(), C, H.ptr(sc), H.ptr(sh), C if aff else 0, 1, rs, dx.data_ptr(), H.ptr(dsc), H.ptr(dsh),
-                   N, Hs, Ws, C, None, 0, 0, 0, H.stream())
+                   N, Hs, Ws, C, None, 0, 0, 0, 0, H.stream())
         H.call("ieagan_conv_wgrad", wd, 1, H.stream())
 
     us2 = timed(separate)
