@@ -313,20 +313,32 @@ __global__ __launch_bounds__(1024) void loss_block_kernel(LossArgs a) {
                 const float B = cw * (-1.f + pos / den) / t;
                 dep[i] = B * ri * si;
                 dpp[i] = B * ci * (-0.5f / fmaxf(pp[i], 1e-16f));
+                // Every DG element has ONE writer per section (the sections are separated by block barriers), so the sums are formed in
+                // a fixed order -- bit-reproducible, unlike LDS float atomics: row i belongs to thread i; the column-wise diagonal terms
+                // (row i's share of d total / d G_jj) are parked in the staging matrix `la` and summed by thread j after a barrier.
                 float dgii = B * ci * (-0.5f / fmaxf(G[i * n + i], 1e-16f));
                 for (int j = 0; j < n; ++j) {
-                    if (j == i) continue;
+                    if (j == i) {
+                        la[i * 65 + j] = 0.f;
+                        continue;
+                    }
                     const float rj = 1.f / fmaxf(sqrtf(G[j * n + j]), 1e-8f);
                     const float cij = G[i * n + j] * ri * rj;
                     const float A = cw * __expf(cij / t) / den / t;           // d total / d cos_ij (row i)
-                    atomicAdd(&DG[i * n + j], A * ri * rj);
+                    DG[i * n + j] += A * ri * rj;
                     dgii += A * cij * (-0.5f / fmaxf(G[i * n + i], 1e-16f));
-                    atomicAdd(&DG[j * n + j], A * cij * (-0.5f / fmaxf(G[j * n + j], 1e-16f)));
+                    la[i * 65 + j] = A * cij * (-0.5f / fmaxf(G[j * n + j], 1e-16f));
                 }
-                atomicAdd(&DG[i * n + i], dgii);
+                DG[i * n + i] += dgii;
             }
             part = block_reduce_sum(part, red);
             if (tid == 0) sc[4] = part / n;
+            __syncthreads();
+            for (int j = tid; j < n; j += blockDim.x) {
+                float s = 0.f;
+                for (int i = 0; i < n; ++i) s += la[i * 65 + j];
+                DG[j * n + j] += s;
+            }
         }
         __syncthreads();
 
@@ -344,10 +356,18 @@ __global__ __launch_bounds__(1024) void loss_block_kernel(LossArgs a) {
                 const int i = idx / n, j = idx - i * n;
                 if (i < j) {
                     const float wgt = w_u * __expf(-2.f * fmaxf(G[i * n + i] + G[j * n + j] - 2.f * G[idx], 0.f)) / tot;  // d/d(-2 d2)
-                    atomicAdd(&DG[i * n + i], -2.f * wgt);
-                    atomicAdd(&DG[j * n + j], -2.f * wgt);
-                    atomicAdd(&DG[idx], 4.f * wgt);
+                    DG[idx] += 4.f * wgt;                       // (one writer per element)
                 }
+            }
+            // diagonal: DG_kk -= 2 sum_{j != k} wgt_kj, by thread k in a fixed order (was: two float atomics per pair)
+            for (int k = tid; k < n; k += blockDim.x) {
+                float s = 0.f;
+                for (int j = 0; j < n; ++j) {
+                    if (j == k) continue;
+                    const int lo = min(k, j), hi = max(k, j);
+                    s += w_u * __expf(-2.f * fmaxf(G[lo * n + lo] + G[hi * n + hi] - 2.f * G[lo * n + hi], 0.f)) / tot;
+                }
+                DG[k * n + k] += -2.f * s;
             }
         }
         __syncthreads();
@@ -371,7 +391,7 @@ __global__ __launch_bounds__(1024) void loss_block_kernel(LossArgs a) {
                     const float logp = G[i * n + j] - lsef, logt = R[i * n + j] - lser;
                     const float T = __expf(logt);
                     part += T * (logt - logp);
-                    atomicAdd(&DG[i * n + j], w_i * (__expf(logp) - T) / n);
+                    DG[i * n + j] += w_i * (__expf(logp) - T) / n;              // row i belongs to thread i
                 }
             }
             part = block_reduce_sum(part, red);
