@@ -353,21 +353,28 @@ def kernel_report(res, m, args):
         try:        # cross-check of the launchers' 8(d) byte accounting against the architecture calculator
             import arch_calc
             calc = arch_calc.step_family_gbytes()
-            got = {"conv1x1_fwd_dgrad": 0.0, "conv3x3_fwd_dgrad": 0.0, "conv1x1_wgrad": 0.0, "conv3x3_wgrad": 0.0, "conv1x1_bwd_fused": 0.0}
+            got = {"conv1x1_fwd_dgrad": 0.0, "conv3x3_fwd_dgrad": 0.0, "conv1x1_wgrad": 0.0, "conv3x3_wgrad": 0.0, "conv1x1_bwd_fused": 0.0,
+                   "conv3x3_bwd_fused": 0.0}
             for r in recs:
                 fam = r["name"].split(" ")[0]
                 key = {"conv1x1_gather": "conv1x1_fwd_dgrad", "conv3x3_halo": "conv3x3_fwd_dgrad", "conv3x3_gather": "conv3x3_fwd_dgrad",
-                       "conv1x1_wgrad": "conv1x1_wgrad", "conv3x3_wgrad": "conv3x3_wgrad", "conv1x1_bwd": "conv1x1_bwd_fused"}.get(fam)
+                       "conv1x1_wgrad": "conv1x1_wgrad", "conv3x3_wgrad": "conv3x3_wgrad", "conv1x1_bwd": "conv1x1_bwd_fused",
+                       "conv3x3_bwd": "conv3x3_bwd_fused"}.get(fam)
                 if key:
                     got[key] += (r.get("bytes_min") or r["bytes"]) / prof_steps / 1e9
-            res["arch_calc_check"] = {k: {"calculator_gbytes": calc[k], "measured_launches_gbytes": got[k]} for k in got if k in calc}
-            for k in ("conv1x1_fwd_dgrad", "conv3x3_fwd_dgrad"):      # dgrad launches of resampled layers: both operands at the
-                res["arch_calc_check"][k]["calculator_gbytes_dgrad_as_launched"] = calc[k + "_as_launched"]      # layer's resolution
-            # the fused 1x1 backward launches carry the dgrad AND the wgrad bytes of their layers: the three 1x1 families together
-            # must reproduce the calculator's 1x1 forward + dgrad + wgrad total
-            res["arch_calc_check"]["conv1x1_all"] = {
-                "calculator_gbytes": calc["conv1x1_fwd_dgrad_as_launched"] + calc["conv1x1_wgrad"],
-                "measured_launches_gbytes": got["conv1x1_fwd_dgrad"] + got["conv1x1_wgrad"] + got["conv1x1_bwd_fused"]}
+            # The fused backward launches carry the dgrad AND the wgrad bytes of their layers, so the per-family figures no longer line up
+            # one to one: what must agree is, per kernel size, ALL conv launches together against the calculator's forward + dgrad (as
+            # launched) + wgrad total -- for the 1x1 layers minus the share that runs inside d_stem (first DBlock's conv1 / conv_sc).
+            def both(calc_gb, meas_gb):
+                return {"calculator_gbytes": calc_gb, "measured_launches_gbytes": meas_gb, "agree_within_3pct": abs(meas_gb - calc_gb) <= 0.03 * calc_gb}
+            res["arch_calc_check"] = {
+                "conv1x1_all": both(calc["conv1x1_fwd_dgrad_as_launched"] + calc["conv1x1_wgrad"] - calc["d_stem_1x1"],
+                                    got["conv1x1_fwd_dgrad"] + got["conv1x1_wgrad"] + got["conv1x1_bwd_fused"]),
+                "conv3x3_all": both(calc["conv3x3_fwd_dgrad_as_launched"] + calc["conv3x3_wgrad"],
+                                    got["conv3x3_fwd_dgrad"] + got["conv3x3_wgrad"] + got["conv3x3_bwd_fused"]),
+                "per_family_measured_gbytes": got, "d_stem_1x1_calculator_gbytes": calc["d_stem_1x1"]}
+            if not all(v["agree_within_3pct"] for k, v in res["arch_calc_check"].items() if isinstance(v, dict) and "agree_within_3pct" in v):
+                print("bench: arch_calc_check DISAGREES: " + json.dumps(res["arch_calc_check"]), file=sys.stderr)
         except Exception as e:
             res["arch_calc_check"] = f"unavailable: {e}"
 

@@ -41,21 +41,25 @@ bool prof_tags_on() { return g_prof_on && g_prof_tags; }
 static thread_local ConvPlanCtx g_plan = {false, 0};
 ConvPlanCtx& conv_plan_ctx() { return g_plan; }
 
-ProfScope::ProfScope(const char* name, double flops, double bytes, hipStream_t s, const char* tag, double bytes_min) : slot(-1), stream(s) {
+ProfScope::ProfScope(const char* nm, double fl, double by, hipStream_t s, const char* tag, double bmin)
+    : active(false), stream(s), ev_a(nullptr), ev_b(nullptr), flops(fl), bytes(by), bytes_min(bmin < 0.0 ? by : bmin) {
     if (!g_prof_on || g_plan.on) return;
-    ProfEvt e{std::string(name), nullptr, nullptr, flops, bytes, bytes_min < 0.0 ? bytes : bytes_min};
-    if (g_prof_tags && tag != nullptr) e.name += std::string(" ") + tag;
-    if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
-    hipEventRecord(e.a, s);
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    g_prof.push_back(e);
-    slot = (int)g_prof.size() - 1;
+    if (g_prof_tags && tag != nullptr) snprintf(name, sizeof(name), "%s %s", nm, tag);
+    else snprintf(name, sizeof(name), "%s", nm);
+    if (hipEventCreate(&ev_a) != hipSuccess) return;
+    if (hipEventCreate(&ev_b) != hipSuccess) {
+        hipEventDestroy(ev_a);
+        return;
+    }
+    hipEventRecord(ev_a, s);
+    active = true;
 }
 
 ProfScope::~ProfScope() {
-    if (slot < 0) return;
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    hipEventRecord(g_prof[slot].b, stream);
+    if (!active) return;
+    hipEventRecord(ev_b, stream);
+    std::lock_guard<std::mutex> lk(g_prof_mu);        // the finished record changes hands here; collect / reset own it from now on
+    g_prof.push_back(ProfEvt{std::string(name), ev_a, ev_b, flops, bytes, bytes_min});
 }
 
 extern "C" int ieagan_prof_enable(int on) {      // 0 off, 1 per kernel family, 2 per kernel family + shape tag

@@ -229,59 +229,84 @@ extern "C" int ieagan_prologue_bwd(const void* da, const void* x, int Cx, const 
 }
 
 // ------------------------------------------------------------------------------------------------
-// bn_finalize (one small block; C <= 512, N <= 64 images)
-//   stats     [STAT_REPL][2][C] replicated (sum, sumsq) of the normalised tensor, count = N*H*W
+// bn_finalize
+//   stats     [E][R][2][C] (sum, sumsq) slots of the normalised tensor (R = the producer's blocks per event: single-adder slots, see
+//             ieagan_conv_desc.stats_slots), count = elements per channel of one event
 //   gain/bias per-(n,c) conditional terms with row stride ld (ccbn: scale uses 1+gain) or per-channel
 //             parameters with ld == 0 (plain bn: scale uses gain)
 //   training: batch statistics + running-stat update (momentum, unbiased variance for the running
 //             update, as F.batch_norm); eval: running statistics
+// A block = 32 channels x 16 phases x {sum, sumsq}: lane j of a phase reads column j of slot r -- consecutive lanes, consecutive floats
+// (one wave per channel with the lanes striding over the slots touched 64 cache lines per load: 7 -> 10 us per launch once the slot
+// count followed the producer's grid).  The slots are folded in a FIXED order: phase ph takes r = ph, ph + 16, ... sequentially, the 16
+// phase partials are added in order -- bit-reproducible for any R.
 // ------------------------------------------------------------------------------------------------
-// one wave per channel: lanes fold the statistics replicas of every event, then fan out over the images
-__global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __restrict__ stats, float count, const float* __restrict__ gain,
+#define BNF_CH 32
+#define BNF_PH 16
+__global__ __launch_bounds__(1024) void bn_finalize_fwd_kernel(const float* __restrict__ stats, float count, const float* __restrict__ gain,
                                        const float* __restrict__ bias, int ld, int plus_one, float eps, float momentum,
                                        int training, float* __restrict__ run_mean, float* __restrict__ run_var,
                                        float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_rstd,
                                        int N, int C, int E, int R) {
-    const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= C) return;
+    __shared__ float part[BNF_PH][2 * BNF_CH];
+    __shared__ float ms[2][BNF_CH];
+    const int t = threadIdx.x, ph = t >> 6, j = t & 63, cj = j & (BNF_CH - 1), which = j >> 5;
+    const int c0 = blockIdx.x * BNF_CH, c = c0 + cj;
+    const bool valid = c < C;
     const int npe = N / E;
     const int rows = (ld == 0 && E == 1) ? 1 : N;
-    float upd_mean = 0.f, upd_var = 0.f;
+    float upd_mean = 0.f, upd_var = 0.f;             // (threads t < BNF_CH)
     for (int e = 0; e < E; ++e) {
-        float mean, var;
         if (training) {
-            float s1 = 0.f, s2 = 0.f;
-            // R slots, folded in a fixed order (lane-strided partial sums, then the wave butterfly): bit-reproducible for ANY slot count
-            const float* se = stats + (long)e * R * 2 * C;
-            for (int r = lane; r < R; r += 64) {
-                s1 += se[(long)r * 2 * C + c];
-                s2 += se[(long)r * 2 * C + C + c];
+            float acc = 0.f;
+            if (valid) {
+                const float* p = stats + (long)e * R * 2 * C + (long)which * C + c;
+#pragma unroll 8
+                for (int r = ph; r < R; r += BNF_PH) acc += p[(long)r * 2 * C];
             }
-            s1 = wave_sum(s1);
-            s2 = wave_sum(s2);
-            mean = s1 / count;
-            var = fmaxf(s2 / count - mean * mean, 0.f);
-            upd_mean += mean;
-            upd_var += var * (count / fmaxf(count - 1.f, 1.f));
-        } else {
-            mean = run_mean[c];
-            var = run_var[c];
+            part[ph][j] = acc;
+            __syncthreads();
+            if (t < 2 * BNF_CH) {
+                float sacc = 0.f;
+#pragma unroll
+                for (int k = 0; k < BNF_PH; ++k) sacc += part[k][t];
+                part[0][t] = sacc;          // (row 0, column t: read above by this thread only)
+            }
+            __syncthreads();
         }
-        const float rstd = rsqrtf(var + eps);
-        if (lane == 0) {
+        if (t < BNF_CH && valid) {
+            float mean, var;
+            if (training) {
+                const float s1 = part[0][t], s2 = part[0][BNF_CH + t];
+                mean = s1 / count;
+                var = fmaxf(s2 / count - mean * mean, 0.f);
+                upd_mean += mean;
+                upd_var += var * (count / fmaxf(count - 1.f, 1.f));
+            } else {
+                mean = run_mean[c];
+                var = run_var[c];
+            }
+            const float rstd = rsqrtf(var + eps);
+            ms[0][t] = mean;
+            ms[1][t] = rstd;
             mean_rstd[(long)e * 2 * C + c] = mean;
             mean_rstd[(long)e * 2 * C + C + c] = rstd;
         }
+        __syncthreads();
+        // fan-out over the images of this event: thread -> (image, channel), 32 consecutive channels per image row
         const int n0 = (rows == 1) ? 0 : e * npe, n1 = (rows == 1) ? 1 : (e + 1) * npe;
-        for (int n = n0 + lane; n < n1; n += 64) {
-            const float g = gain[(long)n * ld + c] + (plus_one ? 1.f : 0.f);
-            const float sc = rstd * g;
-            scale[(long)n * C + c] = sc;
-            shift[(long)n * C + c] = bias[(long)n * ld + c] - mean * sc;
+        for (int idx = t; idx < (n1 - n0) * BNF_CH; idx += 1024) {
+            const int n = n0 + idx / BNF_CH, cc = idx % BNF_CH;
+            if (c0 + cc < C) {
+                const float g = gain[(long)n * ld + c0 + cc] + (plus_one ? 1.f : 0.f);
+                const float sc = ms[1][cc] * g;
+                scale[(long)n * C + c0 + cc] = sc;
+                shift[(long)n * C + c0 + cc] = bias[(long)n * ld + c0 + cc] - ms[0][cc] * sc;
+            }
         }
+        __syncthreads();
     }
-    if (training && lane == 0) {     // mean of the E per-event momentum updates (E = 1: F.batch_norm's update)
+    if (training && t < BNF_CH && valid) {     // mean of the E per-event momentum updates (E = 1: F.batch_norm's update)
         run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * upd_mean / (float)E;
         run_var[c] = (1.f - momentum) * run_var[c] + momentum * upd_var / (float)E;
     }
@@ -298,57 +323,91 @@ extern "C" int ieagan_bn_finalize_fwd(const float* stats, float count, const flo
     CHECK_ARG(N % E == 0, "bn_finalize: %d images are not %d whole events", N, E);
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof("bn_finalize_fwd", 0.0, 0.0, st);
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, stats, count, gain, bias, ld, plus_one, eps,
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(C, BNF_CH)), dim3(1024), 0, st, stats, count, gain, bias, ld, plus_one, eps,
                        momentum, training, run_mean, run_var, scale, shift, mean_rstd, N, C, E, repl);
     CHECK_LAUNCH("bn_finalize_fwd");
     return 0;
 }
 
-//   dscale/dshift [rows][C]  ->  dgain/dbias [rows][ld-strided slice] (ld==0: [C], summed over the rows), dstat [E][2][C]
-__global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* __restrict__ dscale, const float* __restrict__ dshift,
+//   dscale/dshift [rows][C] (R == 0) or per-image slot accumulators [N][R][2][C] ({sum d, sum d x}, R > 0)
+//   ->  dgain/dbias [rows][ld-strided slice] (ld==0: [C], summed over the rows), dstat [E][2][C]
+// Same block shape as the forward: 32 channels x {d shift, d scale} per 64-lane phase, 16 image phases; every sum in a fixed order.
+#define BNF_NB 64          // images per LDS pass
+__global__ __launch_bounds__(1024) void bn_finalize_bwd_kernel(const float* __restrict__ dscale, const float* __restrict__ dshift,
                                        const float* __restrict__ gain, int ld, int plus_one, const float* __restrict__ mean_rstd,
                                        float count, int training, float* __restrict__ dgain, float* __restrict__ dbias, int ldd,
                                        float* __restrict__ dstat, int N, int C, int E, int R) {
-    const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= C) return;
+    __shared__ float v[BNF_NB][2 * BNF_CH];        // [image][{dt | ds} x channel], then {drstd | dmean} contributions
+    __shared__ float w[BNF_NB][2 * BNF_CH];        // ld == 0: {d gain | d bias} contributions
+    const int t = threadIdx.x, ph = t >> 6, j = t & 63, cj = j & (BNF_CH - 1), which = j >> 5;
+    const int c0 = blockIdx.x * BNF_CH, c = c0 + cj;
+    const bool valid = c < C;
     const int npe = N / E;
     const int rows = (ld == 0 && E == 1 && R == 0) ? 1 : N;
-    float dg_sum = 0.f, db_sum = 0.f;            // ld == 0: per-channel parameters, summed over rows / events
+    float dg_sum = 0.f, db_sum = 0.f;              // ld == 0 (threads t < BNF_CH): per-channel parameters, summed over rows / events
     for (int e = 0; e < E; ++e) {
-        const float mean = mean_rstd[(long)e * 2 * C + c], rstd = mean_rstd[(long)e * 2 * C + C + c];
-        float drstd = 0.f, dmean = 0.f;
         const int n0 = (rows == 1) ? 0 : e * npe, n1 = (rows == 1) ? 1 : (e + 1) * npe;
-        for (int n = n0 + lane; n < n1; n += 64) {
-            const float g = gain[(long)n * ld + c] + (plus_one ? 1.f : 0.f);
-            float ds, dt;
-            if (R > 0) {                             // replicated per-image accumulators of a BatchNorm-backward dgrad launch
-                ds = dt = 0.f;
-                const float* acc = dscale + (long)n * R * 2 * C;
-                for (int r = 0; r < R; ++r) {
-                    dt += acc[(long)r * 2 * C + c];
-                    ds += acc[(long)r * 2 * C + C + c];
+        float drstd = 0.f, dmean = 0.f;            // (threads t < BNF_CH)
+        for (int nb = n0; nb < n1; nb += BNF_NB) {
+            const int ne = min(nb + BNF_NB, n1);
+            // 1. {dt, ds} of every (image, channel): slots folded sequentially
+            for (int n = nb + ph; n < ne; n += BNF_PH) {
+                float acc = 0.f;
+                if (valid) {
+                    if (R > 0) {
+                        const float* p = dscale + ((long)n * R * 2 + which) * C + c;      // slot layout: [0] = sum d (d shift), [1] = sum d x (d scale)
+#pragma unroll 4
+                        for (int r = 0; r < R; ++r) acc += p[(long)r * 2 * C];
+                    } else {
+                        acc = (which ? dscale : dshift)[(long)n * C + c];
+                    }
                 }
-            } else {
-                ds = dscale[(long)n * C + c];
-                dt = dshift[(long)n * C + c];
+                v[n - nb][j] = acc;
             }
-            const float ee = ds - dt * mean;          // d/d(scale) with shift = bias - mean*scale folded in
-            if (ld != 0) {
-                dgain[(long)n * ldd + c] = ee * rstd;
-                dbias[(long)n * ldd + c] = dt;
-            } else {
-                dg_sum += ee * rstd;
-                db_sum += dt;
+            __syncthreads();
+            // 2. per (image, channel): conditional-parameter gradients and the contributions to d rstd / d mean
+            float mean = 0.f, rstd = 0.f;
+            for (int idx = t; idx < (ne - nb) * BNF_CH; idx += 1024) {
+                const int nl = idx / BNF_CH, cc = idx % BNF_CH, n = nb + nl;
+                float a_ = 0.f, b_ = 0.f, g_ = 0.f, h_ = 0.f;
+                if (c0 + cc < C) {
+                    mean = mean_rstd[(long)e * 2 * C + c0 + cc];
+                    rstd = mean_rstd[(long)e * 2 * C + C + c0 + cc];
+                    const float dt = v[nl][cc], ds = v[nl][BNF_CH + cc];
+                    const float g = gain[(long)n * ld + c0 + cc] + (plus_one ? 1.f : 0.f);
+                    const float ee = ds - dt * mean;          // d/d(scale) with shift = bias - mean*scale folded in
+                    if (ld != 0) {
+                        dgain[(long)n * ldd + c0 + cc] = ee * rstd;
+                        dbias[(long)n * ldd + c0 + cc] = dt;
+                    } else {
+                        g_ = ee * rstd;
+                        h_ = dt;
+                    }
+                    a_ = ee * g;
+                    b_ = -dt * rstd * g;
+                }
+                w[nl][cc] = g_;
+                w[nl][BNF_CH + cc] = h_;
+                // (v[nl][cc] / v[nl][BNF_CH + cc] were read by this thread only: overwrite in place)
+                v[nl][cc] = a_;
+                v[nl][BNF_CH + cc] = b_;
             }
-            drstd += ee * g;
-            dmean -= dt * rstd * g;
+            __syncthreads();
+            // 3. channel sums over the images of this pass, in image order
+            if (t < BNF_CH) {
+                for (int nl = 0; nl < ne - nb; ++nl) {
+                    drstd += v[nl][t];
+                    dmean += v[nl][BNF_CH + t];
+                    dg_sum += w[nl][t];
+                    db_sum += w[nl][BNF_CH + t];
+                }
+            }
+            __syncthreads();
         }
-        drstd = wave_sum(drstd);
-        dmean = wave_sum(dmean);
-        if (dstat && lane == 0) {
+        if (dstat && t < BNF_CH && valid) {
             float* de = dstat + (long)e * 2 * C;
             if (training) {
+                const float mean = mean_rstd[(long)e * 2 * C + c], rstd = mean_rstd[(long)e * 2 * C + C + c];
                 const float dvar = -0.5f * rstd * rstd * rstd * drstd;
                 de[C + c] = dvar / count;                          // d sumsq
                 de[c] = (dmean - 2.f * mean * dvar) / count;       // d sum
@@ -358,13 +417,9 @@ __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* __res
             }
         }
     }
-    if (ld == 0) {
-        dg_sum = wave_sum(dg_sum);
-        db_sum = wave_sum(db_sum);
-        if (lane == 0) {
-            dgain[c] = dg_sum;
-            dbias[c] = db_sum;
-        }
+    if (ld == 0 && t < BNF_CH && valid) {
+        dgain[c] = dg_sum;
+        dbias[c] = db_sum;
     }
 }
 
@@ -376,7 +431,7 @@ extern "C" int ieagan_bn_finalize_bwd(const float* dscale, const float* dshift, 
     CHECK_ARG(acc_repl >= 0 && acc_repl <= 4096, "bn_finalize_bwd: bad replica count %d", acc_repl);
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof("bn_finalize_bwd", 0.0, 0.0, st);
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, dscale, dshift, gain, ld, plus_one,
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(C, BNF_CH)), dim3(1024), 0, st, dscale, dshift, gain, ld, plus_one,
                        mean_rstd, count, training, dgain, dbias, ldd, dstat, N, C, E, acc_repl);
     CHECK_LAUNCH("bn_finalize_bwd");
     return 0;

@@ -18,11 +18,18 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 // thread-local last-error text, set by the launchers in api.hip
 void ieagan_set_error(const char* fmt, ...);
 // optional per-kernel event profiling (api.hip); name must be a string literal
+// (the scope OWNS its two events and hands the finished record to the collector in its destructor: a scope that is open on the autograd or
+//  side-stream thread while another thread collects / resets never touches the collector's storage)
 struct ProfScope {
     ProfScope(const char* name, double flops, double bytes, hipStream_t s, const char* tag = nullptr, double bytes_min = -1.0);
     ~ProfScope();
-    int slot;
+    ProfScope(const ProfScope&) = delete;
+    ProfScope& operator=(const ProfScope&) = delete;
+    bool active;
     hipStream_t stream;
+    hipEvent_t ev_a, ev_b;
+    double flops, bytes, bytes_min;
+    char name[96];
 };
 
 bool prof_tags_on();

@@ -310,8 +310,9 @@ class DBlock(nn.Module):
 
     def stem_ok(self, input_conv, x):
         """Can ``ops.DStemFn`` take input_conv + this block's conv1 / conv_sc / pooled shortcut?  (the first block of the shipped
-        ch = 32 discriminator on a map whose height / width are multiples of 8 / 32)"""
-        return (ops.FUSE_D_STEM and x.is_cuda and x.dim() == 4 and x.shape[1] == 1 and x.shape[2] % 8 == 0 and x.shape[3] % 32 == 0
+        ch = 32 discriminator on a map whose height / width are multiples of 8 / 64: the stem's backward runs conv_sc through the fused
+        1x1 backward at the POOLED resolution, whose tiles need (W / 2) % 32 == 0)"""
+        return (ops.FUSE_D_STEM and x.is_cuda and x.dim() == 4 and x.shape[1] == 1 and x.shape[2] % 8 == 0 and x.shape[3] % 64 == 0
                 and input_conv.out_channels == 32 and self.in_channels == 32 and self.out_channels == 64 and self.hidden_channels == 16
                 and self.downsample is not None and not self.preactivation and self.learnable_sc
                 and all(c.bias is not None for c in (input_conv, self.conv1, self.conv_sc)))

@@ -116,6 +116,12 @@ def step_family_gbytes():
         go = sum(l["bytes_out_res"] for l in G if l["taps"] == kind) / 1e9
         do = sum(l["bytes_out_res"] for l in D if l["taps"] == kind) / 1e9
         out[tag + "_fwd_dgrad_as_launched"] = 2 * g + 3 * d + (go + 2 * do + do)
+    # The first DBlock's conv1 and conv_sc run inside d_stem_fwd (all three D forwards) and d_stem_bwd (conv1's dgrad + wgrad in the two
+    # full D backwards; conv_sc's backward is a conv1x1_bwd launch and the dgrad-only pass uses the generic launches): their share of the
+    # 1x1 totals above never shows up in the conv1x1_* families bench.py times
+    stem = [l for l in D if l["name"] in ("D.blocks.0.0.conv1", "D.blocks.0.0.conv_sc")]
+    c1 = [l for l in stem if l["name"].endswith("conv1")]
+    out["d_stem_1x1"] = (3 * sum(l["bytes"] for l in stem) + 2 * sum(l["bytes_out_res"] + l["bytes"] for l in c1)) / 1e9
     return out
 
 

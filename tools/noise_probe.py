@@ -13,21 +13,24 @@ cfg = make_cfg(resolution=res, H_base=hb, clip_norm=1e9, hip_graph=False, ema=Fa
 x, y = O.synth_event(n, res, res * hb, 404).cuda(), torch.arange(n).cuda()
 noise = make_noise(n, res, res * hb, 919)
 runs = []
-settings = [(True, True), (True, True), (False, False), (False, False)]
-for side, two in settings:
+# (weight gradients on the side stream, two-stage accumulation, fused 1x1 backward, fused 3x3 backward)
+settings = [(True, True, True, True), (True, True, True, True), (False, False, True, True), (False, False, False, False),
+            (True, True, False, True), (True, True, True, False)]
+for side, two, f1, f3 in settings:
     g_state, d_state = O.synth_nets(cfg, 111, 222)
     G, D = build_product(cfg, g_state, d_state, "cuda:0")
     z_, y_ = utils.prepare_z_y(n, G.dim_z, cfg["n_classes"], device="cuda:0")
     train = train_fns.GAN_training_function(G, D, model.G_D(G, D), z_, y_, None, {"itr": 1}, cfg, "cuda:0")
-    ops.WGRAD_SIDE_STREAM, ops.TWO_STAGE_WGRAD = side, two
+    ops.WGRAD_SIDE_STREAM, ops.TWO_STAGE_WGRAD, ops.FUSE_1X1_BACKWARD, ops.FUSE_3X3_BACKWARD = side, two, f1, f3
     out = train(x, y, noise=noise)
     torch.cuda.synchronize()
     names = [k for k, _ in G.named_parameters()]
     grads = {k: p.grad.detach().clone() for k, p in G.named_parameters()}
     runs.append((out, G._arena.grad.clone(), grads, D._arena.grad.clone()))
-for a, b in ((0, 1), (2, 3), (0, 2)):
+for a, b in ((0, 1), (0, 2), (0, 3), (0, 4), (0, 5)):
     oa, ga, pa, da = runs[a]
     ob, gb, pb, db = runs[b]
+    print(f"settings {settings[a]} vs {settings[b]}")
     print(f"runs {a} vs {b}: G flat rel {rel_l2(gb, ga):.3e}  D flat rel {rel_l2(db, da):.3e}  losses {oa} {ob}")
     rows = []
     for k in pa:
