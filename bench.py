@@ -288,7 +288,9 @@ def measure(cfg, args, rank, world, local, tag):
         # the dgrad chain): a launch's duration is then its own, as in the rocprofv3 kernel trace, which serialises dispatches too.
         import ops
         prof_steps = min(steps, 3)
-        side, ops.WGRAD_SIDE_STREAM = ops.WGRAD_SIDE_STREAM, False
+        side = [ops.opts_of_net(net).wgrad_side_stream for net in (G, D)]
+        for net in (G, D):              # per-network execution option (ops.ExecOptions): only the two networks being timed change
+            ops.set_options(net, wgrad_side_stream=False)
         _hip.call("ieagan_prof_reset")
         _hip.prof_enable(2 if args.shape_tags else 1)
         for _ in range(prof_steps):
@@ -296,7 +298,8 @@ def measure(cfg, args, rank, world, local, tag):
             train.step_tensor(xs[state["itr"] % n_rot], y)
         torch.cuda.synchronize()
         _hip.prof_enable(False)
-        ops.WGRAD_SIDE_STREAM = side
+        for net, sv in zip((G, D), side):
+            ops.set_options(net, wgrad_side_stream=sv)
     if timing:
         recs = sorted(_hip.prof_collect(), key=lambda r: -r["ms"])
     if world > 1:
@@ -414,7 +417,7 @@ def main():
     torch.cuda.set_device(local)
     if args.serial_wgrad:
         import ops
-        ops.WGRAD_SIDE_STREAM = False
+        ops.DEFAULTS.wgrad_side_stream = False         # seeds the options of every network built below
 
     def cfg_for(which):
         cfg = bench_config(which)

@@ -93,8 +93,10 @@ _SIGS = {
     "ieagan_d_stem_bwd": [C.POINTER(DStemDesc), vp],
     "ieagan_effgrad": [vp, vp, vp, vp, vp, l, i, i, vp],
     "ieagan_prologue_bwd": [vp, vp, i, vp, vp, i, i, i, vp, vp, vp, i, i, i, i, vp, i, i, i, i, vp],
-    "ieagan_bn_finalize_fwd": [vp, f, vp, vp, i, i, f, f, i, vp, vp, vp, vp, vp, i, i, i, i, vp],
-    "ieagan_bn_finalize_bwd": [vp, vp, vp, i, i, vp, f, i, vp, vp, i, vp, i, i, i, i, vp],
+    "ieagan_bn_finalize_fwd": [vp, f, vp, vp, i, i, f, f, i, vp, vp, vp, vp, vp, i, i, i, i, vp, vp],
+    "ieagan_bn_finalize_bwd": [vp, vp, vp, i, i, vp, f, i, vp, vp, i, vp, i, i, i, i, vp, vp],
+    "ieagan_bn_finalize_fwd_scratch": [i, i, i],
+    "ieagan_bn_finalize_bwd_scratch": [i, i, i, i],
     "ieagan_res_bwd": [vp, i, vp, i, i, i, i, i, i, vp],
     "ieagan_nchw_to_nhwc": [vp, vp, vp, i, i, i, i, vp],
     "ieagan_nhwc_to_nchw": [vp, vp, i, i, i, vp],
@@ -158,7 +160,7 @@ def lib():
         for name, sig in _SIGS.items():
             fn = getattr(_lib, name)
             fn.argtypes = sig
-            fn.restype = C.c_long if name.endswith("_workspace") else C.c_int
+            fn.restype = C.c_long if name.endswith(("_workspace", "_scratch")) else C.c_int
     return _lib
 
 

@@ -236,48 +236,104 @@ extern "C" int ieagan_prologue_bwd(const void* da, const void* x, int Cx, const 
 //             parameters with ld == 0 (plain bn: scale uses gain)
 //   training: batch statistics + running-stat update (momentum, unbiased variance for the running
 //             update, as F.batch_norm); eval: running statistics
-// A block = 32 channels x 16 phases x {sum, sumsq}: lane j of a phase reads column j of slot r -- consecutive lanes, consecutive floats
-// (one wave per channel with the lanes striding over the slots touched 64 cache lines per load: 7 -> 10 us per launch once the slot
-// count followed the producer's grid).  The slots are folded in a FIXED order: phase ph takes r = ph, ph + 16, ... sequentially, the 16
-// phase partials are added in order -- bit-reproducible for any R.
+// A block = CH channels x {sum, sumsq} columns x PH slot phases: lane j of a phase reads column j of slot r -- consecutive lanes, consecutive
+// floats.  Every sum has a FIXED order (phase ph takes its slots sequentially, the phase partials and the group partials are added in
+// index order): bit-reproducible for any R.
+// Large R (the producers of the big feature maps run 512 ... 2048 blocks): the slots are split over G block rows (blockIdx.y), each row
+// publishes its partial sums (sc1 stores), and the row whose ticket comes last folds the G partials and does the rest -- one CU pulling
+// 2 R C floats on its own took 10-14 us per launch.  Hand-off as MI355X_MICROARCH.md prescribes for "the workgroup whose add came last":
+// sc1 payload stores, every storing wave's s_waitcnt vmcnt(0), workgroup barrier, ONE agent-scope returning add per workgroup, sc1 loads
+// of the payload by the last workgroup behind a barrier its adding wave joins.
 // ------------------------------------------------------------------------------------------------
 #define BNF_CH 32
-#define BNF_PH 16
+#define BNF_MAXE 16
+#define BNF_SLOTS_PER_ROW 128      // slots one block row folds at most before the work is split (G = ceil(R / 128), <= 16)
+
+__device__ __forceinline__ void sc1_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float sc1_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// ticket of block column `cb`: true for the block row whose add came last (all threads of the block get the same answer)
+__device__ __forceinline__ bool last_row_arrives(int* tick, int cb, int G, int* s_flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's payload stores have left
+    __syncthreads();
+    if (threadIdx.x == 0) *s_flag = (atomicAdd(tick + cb, 1) == G - 1) ? 1 : 0;
+    __syncthreads();
+    return *s_flag != 0;
+}
+
+static inline int bnf_rows(int R) {
+    int g = (R + BNF_SLOTS_PER_ROW - 1) / BNF_SLOTS_PER_ROW;
+    return g < 1 ? 1 : (g > 16 ? 16 : g);
+}
+static inline long bnf_tick_floats(int C) { return ((cdiv(C, 16) + 63) / 64) * 64; }
+
+template <int CH>
 __global__ __launch_bounds__(1024) void bn_finalize_fwd_kernel(const float* __restrict__ stats, float count, const float* __restrict__ gain,
                                        const float* __restrict__ bias, int ld, int plus_one, float eps, float momentum,
                                        int training, float* __restrict__ run_mean, float* __restrict__ run_var,
                                        float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_rstd,
-                                       int N, int C, int E, int R) {
-    __shared__ float part[BNF_PH][2 * BNF_CH];
-    __shared__ float ms[2][BNF_CH];
-    const int t = threadIdx.x, ph = t >> 6, j = t & 63, cj = j & (BNF_CH - 1), which = j >> 5;
-    const int c0 = blockIdx.x * BNF_CH, c = c0 + cj;
+                                       int N, int C, int E, int R, float* __restrict__ scratch, long tick_floats) {
+    constexpr int COLS = 2 * CH, PH = 1024 / COLS;
+    __shared__ float part[PH][COLS];
+    __shared__ float tot[BNF_MAXE][COLS];
+    __shared__ float ms[2][CH];
+    __shared__ int s_flag;
+    const int t = threadIdx.x, ph = t / COLS, j = t % COLS, cj = j % CH, which = j / CH;
+    const int cb = blockIdx.x, g = blockIdx.y, G = gridDim.y;
+    const int c0 = cb * CH, c = c0 + cj;
     const bool valid = c < C;
     const int npe = N / E;
     const int rows = (ld == 0 && E == 1) ? 1 : N;
-    float upd_mean = 0.f, upd_var = 0.f;             // (threads t < BNF_CH)
-    for (int e = 0; e < E; ++e) {
-        if (training) {
+    if (training) {
+        const int Rg = (R + G - 1) / G, r_lo = g * Rg, r_hi = min(R, r_lo + Rg);
+        for (int e = 0; e < E; ++e) {
             float acc = 0.f;
-            if (valid) {
+            if (valid && r_lo < r_hi) {
+                // 16 independent loads in flight, then added in slot order
                 const float* p = stats + (long)e * R * 2 * C + (long)which * C + c;
-#pragma unroll 8
-                for (int r = ph; r < R; r += BNF_PH) acc += p[(long)r * 2 * C];
+                for (int r0 = r_lo + ph; r0 < r_hi; r0 += 16 * PH) {
+                    float buf[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int r = r0 + k * PH;
+                        buf[k] = p[(long)min(r, r_hi - 1) * 2 * C];
+                        if (r >= r_hi) buf[k] = 0.f;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) acc += buf[k];
+                }
             }
             part[ph][j] = acc;
             __syncthreads();
-            if (t < 2 * BNF_CH) {
+            if (t < COLS) {
                 float sacc = 0.f;
 #pragma unroll
-                for (int k = 0; k < BNF_PH; ++k) sacc += part[k][t];
-                part[0][t] = sacc;          // (row 0, column t: read above by this thread only)
+                for (int k = 0; k < PH; ++k) sacc += part[k][t];
+                if (G == 1) tot[e][t] = sacc;
+                else if (valid) sc1_store(scratch + tick_floats + ((long)e * G + g) * 2 * C + (long)which * C + c, sacc);
             }
             __syncthreads();
         }
-        if (t < BNF_CH && valid) {
+        if (G > 1) {
+            if (!last_row_arrives((int*)scratch, cb, G, &s_flag)) return;
+            if (t < COLS && valid) {
+                for (int e = 0; e < E; ++e) {
+                    float sacc = 0.f;
+                    for (int gg = 0; gg < G; ++gg) sacc += sc1_load(scratch + tick_floats + ((long)e * G + gg) * 2 * C + (long)which * C + c);
+                    tot[e][t] = sacc;
+                }
+            }
+            __syncthreads();
+        }
+    } else if (g != 0) {
+        return;
+    }
+    float upd_mean = 0.f, upd_var = 0.f;             // (threads t < CH)
+    for (int e = 0; e < E; ++e) {
+        if (t < CH && valid) {
             float mean, var;
             if (training) {
-                const float s1 = part[0][t], s2 = part[0][BNF_CH + t];
+                const float s1 = tot[e][t], s2 = tot[e][CH + t];
                 mean = s1 / count;
                 var = fmaxf(s2 / count - mean * mean, 0.f);
                 upd_mean += mean;
@@ -293,71 +349,113 @@ __global__ __launch_bounds__(1024) void bn_finalize_fwd_kernel(const float* __re
             mean_rstd[(long)e * 2 * C + C + c] = rstd;
         }
         __syncthreads();
-        // fan-out over the images of this event: thread -> (image, channel), 32 consecutive channels per image row
+        // fan-out over the images of this event: thread -> (image, channel), CH consecutive channels per image row
         const int n0 = (rows == 1) ? 0 : e * npe, n1 = (rows == 1) ? 1 : (e + 1) * npe;
-        for (int idx = t; idx < (n1 - n0) * BNF_CH; idx += 1024) {
-            const int n = n0 + idx / BNF_CH, cc = idx % BNF_CH;
+        for (int idx = t; idx < (n1 - n0) * CH; idx += 1024) {
+            const int n = n0 + idx / CH, cc = idx % CH;
             if (c0 + cc < C) {
-                const float g = gain[(long)n * ld + c0 + cc] + (plus_one ? 1.f : 0.f);
-                const float sc = ms[1][cc] * g;
+                const float gg = gain[(long)n * ld + c0 + cc] + (plus_one ? 1.f : 0.f);
+                const float sc = ms[1][cc] * gg;
                 scale[(long)n * C + c0 + cc] = sc;
                 shift[(long)n * C + c0 + cc] = bias[(long)n * ld + c0 + cc] - ms[0][cc] * sc;
             }
         }
         __syncthreads();
     }
-    if (training && t < BNF_CH && valid) {     // mean of the E per-event momentum updates (E = 1: F.batch_norm's update)
+    if (training && t < CH && valid) {     // mean of the E per-event momentum updates (E = 1: F.batch_norm's update)
         run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * upd_mean / (float)E;
         run_var[c] = (1.f - momentum) * run_var[c] + momentum * upd_var / (float)E;
     }
 }
 
+extern "C" long ieagan_bn_finalize_fwd_scratch(int C, int E, int repl) {
+    if (repl == 0) repl = STAT_REPL;
+    const int G = bnf_rows(repl);
+    return G <= 1 ? 0 : bnf_tick_floats(C) + (long)(E < 1 ? 1 : E) * G * 2 * C;
+}
+
 extern "C" int ieagan_bn_finalize_fwd(const float* stats, float count, const float* gain, const float* bias, int ld,
                                       int plus_one, float eps, float momentum, int training, float* run_mean,
                                       float* run_var, float* scale, float* shift, float* mean_rstd, int N, int C, int E,
-                                      int repl, void* stream) {
+                                      int repl, float* scratch, void* stream) {
     CHECK_ARG(!training || stats != nullptr, "bn_finalize: training mode needs batch statistics");
     CHECK_ARG(repl >= 0, "bn_finalize: bad slot count %d", repl);
     if (repl == 0) repl = STAT_REPL;
     if (E < 1) E = 1;
-    CHECK_ARG(N % E == 0, "bn_finalize: %d images are not %d whole events", N, E);
+    CHECK_ARG(N % E == 0 && E <= BNF_MAXE, "bn_finalize: %d images are not %d (<= %d) whole events", N, E, BNF_MAXE);
+    int G = training ? bnf_rows(repl) : 1;
+    if (scratch == nullptr) G = 1;                 // no hand-off space: one block row folds everything (correct, slower for large R)
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof("bn_finalize_fwd", 0.0, 0.0, st);
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv(C, BNF_CH)), dim3(1024), 0, st, stats, count, gain, bias, ld, plus_one, eps,
-                       momentum, training, run_mean, run_var, scale, shift, mean_rstd, N, C, E, repl);
+    const long tkf = bnf_tick_floats(C);
+    if (C <= 16)
+        hipLaunchKernelGGL((bn_finalize_fwd_kernel<16>), dim3(cdiv(C, 16), G), dim3(1024), 0, st, stats, count, gain, bias, ld, plus_one, eps,
+                           momentum, training, run_mean, run_var, scale, shift, mean_rstd, N, C, E, repl, scratch, tkf);
+    else
+        hipLaunchKernelGGL((bn_finalize_fwd_kernel<BNF_CH>), dim3(cdiv(C, BNF_CH), G), dim3(1024), 0, st, stats, count, gain, bias, ld, plus_one, eps,
+                           momentum, training, run_mean, run_var, scale, shift, mean_rstd, N, C, E, repl, scratch, tkf);
     CHECK_LAUNCH("bn_finalize_fwd");
     return 0;
 }
 
 //   dscale/dshift [rows][C] (R == 0) or per-image slot accumulators [N][R][2][C] ({sum d, sum d x}, R > 0)
 //   ->  dgain/dbias [rows][ld-strided slice] (ld==0: [C], summed over the rows), dstat [E][2][C]
-// Same block shape as the forward: 32 channels x {d shift, d scale} per 64-lane phase, 16 image phases; every sum in a fixed order.
+// Block = 32 channels x {d shift, d scale} per 64-lane phase, 16 image phases; the images of an event are split over G block rows (each row
+// owns whole images: their d gain / d bias rows leave directly), the per-channel sums over the images (d rstd, d mean; ld == 0: d gain,
+// d bias) are published per row and folded by the row whose ticket comes last.  Every sum in a fixed order.
 #define BNF_NB 64          // images per LDS pass
+#define BNF_IMG_PER_ROW 8  // images one block row takes at most before the work is split (G <= 8)
+static inline int bnb_rows(int npe, int R, int rows) {
+    if (rows == 1 || R == 0) return 1;
+    int g = (npe + BNF_IMG_PER_ROW - 1) / BNF_IMG_PER_ROW;
+    return g < 1 ? 1 : (g > 8 ? 8 : g);
+}
+
 __global__ __launch_bounds__(1024) void bn_finalize_bwd_kernel(const float* __restrict__ dscale, const float* __restrict__ dshift,
                                        const float* __restrict__ gain, int ld, int plus_one, const float* __restrict__ mean_rstd,
                                        float count, int training, float* __restrict__ dgain, float* __restrict__ dbias, int ldd,
-                                       float* __restrict__ dstat, int N, int C, int E, int R) {
+                                       float* __restrict__ dstat, int N, int C, int E, int R, float* __restrict__ scratch, long tick_floats) {
     __shared__ float v[BNF_NB][2 * BNF_CH];        // [image][{dt | ds} x channel], then {drstd | dmean} contributions
     __shared__ float w[BNF_NB][2 * BNF_CH];        // ld == 0: {d gain | d bias} contributions
+    __shared__ int s_flag;
     const int t = threadIdx.x, ph = t >> 6, j = t & 63, cj = j & (BNF_CH - 1), which = j >> 5;
-    const int c0 = blockIdx.x * BNF_CH, c = c0 + cj;
+    const int cb = blockIdx.x, g = blockIdx.y, G = gridDim.y;
+    const int c0 = cb * BNF_CH, c = c0 + cj;
     const bool valid = c < C;
     const int npe = N / E;
     const int rows = (ld == 0 && E == 1 && R == 0) ? 1 : N;
     float dg_sum = 0.f, db_sum = 0.f;              // ld == 0 (threads t < BNF_CH): per-channel parameters, summed over rows / events
-    for (int e = 0; e < E; ++e) {
-        const int n0 = (rows == 1) ? 0 : e * npe, n1 = (rows == 1) ? 1 : (e + 1) * npe;
-        float drstd = 0.f, dmean = 0.f;            // (threads t < BNF_CH)
+    float drstd_e[BNF_MAXE], dmean_e[BNF_MAXE];    // (threads t < BNF_CH; G == 1: this block's sums ARE the totals)
+#pragma unroll
+    for (int e = 0; e < BNF_MAXE; ++e) drstd_e[e] = dmean_e[e] = 0.f;
+#pragma unroll
+    for (int e = 0; e < BNF_MAXE; ++e) {
+        if (e >= E) break;
+        int n0 = (rows == 1) ? 0 : e * npe, n1 = (rows == 1) ? 1 : (e + 1) * npe;
+        if (G > 1) {                                // this row's images of the event
+            const int ipr = (npe + G - 1) / G;
+            n0 = min(e * npe + g * ipr, n1);
+            n1 = min(n0 + ipr, n1);
+        }
+        float drstd = 0.f, dmean = 0.f, dg_e = 0.f, db_e = 0.f;
         for (int nb = n0; nb < n1; nb += BNF_NB) {
             const int ne = min(nb + BNF_NB, n1);
             // 1. {dt, ds} of every (image, channel): slots folded sequentially
-            for (int n = nb + ph; n < ne; n += BNF_PH) {
+            for (int n = nb + ph; n < ne; n += 16) {
                 float acc = 0.f;
                 if (valid) {
                     if (R > 0) {
                         const float* p = dscale + ((long)n * R * 2 + which) * C + c;      // slot layout: [0] = sum d (d shift), [1] = sum d x (d scale)
-#pragma unroll 4
-                        for (int r = 0; r < R; ++r) acc += p[(long)r * 2 * C];
+                        for (int r0 = 0; r0 < R; r0 += 16) {        // 16 independent loads in flight, added in slot order
+                            float buf[16];
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) {
+                                buf[k] = p[(long)min(r0 + k, R - 1) * 2 * C];
+                                if (r0 + k >= R) buf[k] = 0.f;
+                            }
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) acc += buf[k];
+                        }
                     } else {
                         acc = (which ? dscale : dshift)[(long)n * C + c];
                     }
@@ -366,15 +464,13 @@ __global__ __launch_bounds__(1024) void bn_finalize_bwd_kernel(const float* __re
             }
             __syncthreads();
             // 2. per (image, channel): conditional-parameter gradients and the contributions to d rstd / d mean
-            float mean = 0.f, rstd = 0.f;
             for (int idx = t; idx < (ne - nb) * BNF_CH; idx += 1024) {
                 const int nl = idx / BNF_CH, cc = idx % BNF_CH, n = nb + nl;
                 float a_ = 0.f, b_ = 0.f, g_ = 0.f, h_ = 0.f;
                 if (c0 + cc < C) {
-                    mean = mean_rstd[(long)e * 2 * C + c0 + cc];
-                    rstd = mean_rstd[(long)e * 2 * C + C + c0 + cc];
+                    const float mean = mean_rstd[(long)e * 2 * C + c0 + cc], rstd = mean_rstd[(long)e * 2 * C + C + c0 + cc];
                     const float dt = v[nl][cc], ds = v[nl][BNF_CH + cc];
-                    const float g = gain[(long)n * ld + c0 + cc] + (plus_one ? 1.f : 0.f);
+                    const float gg = gain[(long)n * ld + c0 + cc] + (plus_one ? 1.f : 0.f);
                     const float ee = ds - dt * mean;          // d/d(scale) with shift = bias - mean*scale folded in
                     if (ld != 0) {
                         dgain[(long)n * ldd + c0 + cc] = ee * rstd;
@@ -383,8 +479,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_bwd_kernel(const float* __re
                         g_ = ee * rstd;
                         h_ = dt;
                     }
-                    a_ = ee * g;
-                    b_ = -dt * rstd * g;
+                    a_ = ee * gg;
+                    b_ = -dt * rstd * gg;
                 }
                 w[nl][cc] = g_;
                 w[nl][BNF_CH + cc] = h_;
@@ -398,41 +494,89 @@ __global__ __launch_bounds__(1024) void bn_finalize_bwd_kernel(const float* __re
                 for (int nl = 0; nl < ne - nb; ++nl) {
                     drstd += v[nl][t];
                     dmean += v[nl][BNF_CH + t];
-                    dg_sum += w[nl][t];
-                    db_sum += w[nl][BNF_CH + t];
+                    dg_e += w[nl][t];
+                    db_e += w[nl][BNF_CH + t];
                 }
             }
             __syncthreads();
         }
-        if (dstat && t < BNF_CH && valid) {
-            float* de = dstat + (long)e * 2 * C;
-            if (training) {
-                const float mean = mean_rstd[(long)e * 2 * C + c], rstd = mean_rstd[(long)e * 2 * C + C + c];
-                const float dvar = -0.5f * rstd * rstd * rstd * drstd;
-                de[C + c] = dvar / count;                          // d sumsq
-                de[c] = (dmean - 2.f * mean * dvar) / count;       // d sum
+        if (t < BNF_CH && valid) {
+            if (G == 1) {
+                drstd_e[e] = drstd;
+                dmean_e[e] = dmean;
+                dg_sum += dg_e;
+                db_sum += db_e;
             } else {
-                de[c] = 0.f;
-                de[C + c] = 0.f;
+                float* pay = scratch + tick_floats + (((long)e * G + g) * 4) * C + c;
+                sc1_store(pay, drstd);
+                sc1_store(pay + C, dmean);
+                sc1_store(pay + 2 * C, dg_e);
+                sc1_store(pay + 3 * C, db_e);
             }
         }
     }
-    if (ld == 0 && t < BNF_CH && valid) {
-        dgain[c] = dg_sum;
-        dbias[c] = db_sum;
+    if (G > 1) {
+        if (!last_row_arrives((int*)scratch, cb, G, &s_flag)) return;
+        if (t < BNF_CH && valid) {
+#pragma unroll
+            for (int e = 0; e < BNF_MAXE; ++e) {
+                if (e >= E) break;
+                float a_ = 0.f, b_ = 0.f;
+                for (int gg = 0; gg < G; ++gg) {
+                    const float* pay = scratch + tick_floats + (((long)e * G + gg) * 4) * C + c;
+                    a_ += sc1_load(pay);
+                    b_ += sc1_load(pay + C);
+                    dg_sum += sc1_load(pay + 2 * C);
+                    db_sum += sc1_load(pay + 3 * C);
+                }
+                drstd_e[e] = a_;
+                dmean_e[e] = b_;
+            }
+        }
     }
+    if (t < BNF_CH && valid) {
+        if (dstat) {
+#pragma unroll
+            for (int e = 0; e < BNF_MAXE; ++e) {
+                if (e >= E) break;
+                float* de = dstat + (long)e * 2 * C;
+                if (training) {
+                    const float mean = mean_rstd[(long)e * 2 * C + c], rstd = mean_rstd[(long)e * 2 * C + C + c];
+                    const float dvar = -0.5f * rstd * rstd * rstd * drstd_e[e];
+                    de[C + c] = dvar / count;                          // d sumsq
+                    de[c] = (dmean_e[e] - 2.f * mean * dvar) / count;  // d sum
+                } else {
+                    de[c] = 0.f;
+                    de[C + c] = 0.f;
+                }
+            }
+        }
+        if (ld == 0) {
+            dgain[c] = dg_sum;
+            dbias[c] = db_sum;
+        }
+    }
+}
+
+extern "C" long ieagan_bn_finalize_bwd_scratch(int N, int C, int E, int acc_repl) {
+    if (E < 1) E = 1;
+    const int G = bnb_rows(N / E, acc_repl, N);
+    return G <= 1 ? 0 : bnf_tick_floats(C) + (long)E * G * 4 * C;
 }
 
 extern "C" int ieagan_bn_finalize_bwd(const float* dscale, const float* dshift, const float* gain, int ld, int plus_one,
                                       const float* mean_rstd, float count, int training, float* dgain, float* dbias,
-                                      int ldd, float* dstat, int N, int C, int E, int acc_repl, void* stream) {
+                                      int ldd, float* dstat, int N, int C, int E, int acc_repl, float* scratch, void* stream) {
     if (E < 1) E = 1;
-    CHECK_ARG(N % E == 0, "bn_finalize_bwd: %d images are not %d whole events", N, E);
+    CHECK_ARG(N % E == 0 && E <= BNF_MAXE, "bn_finalize_bwd: %d images are not %d (<= %d) whole events", N, E, BNF_MAXE);
     CHECK_ARG(acc_repl >= 0 && acc_repl <= 4096, "bn_finalize_bwd: bad replica count %d", acc_repl);
+    const int rows = (ld == 0 && E == 1 && acc_repl == 0) ? 1 : N;
+    int G = bnb_rows(N / E, acc_repl, rows);
+    if (scratch == nullptr) G = 1;
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof("bn_finalize_bwd", 0.0, 0.0, st);
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(C, BNF_CH)), dim3(1024), 0, st, dscale, dshift, gain, ld, plus_one,
-                       mean_rstd, count, training, dgain, dbias, ldd, dstat, N, C, E, acc_repl);
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv(C, BNF_CH), G), dim3(1024), 0, st, dscale, dshift, gain, ld, plus_one,
+                       mean_rstd, count, training, dgain, dbias, ldd, dstat, N, C, E, acc_repl, scratch, bnf_tick_floats(C));
     CHECK_LAUNCH("bn_finalize_bwd");
     return 0;
 }

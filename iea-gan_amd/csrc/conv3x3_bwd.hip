@@ -81,10 +81,10 @@ __device__ __forceinline__ bf16x8 b3_frag_T_up(const char* lds, int stride_bytes
     return f;
 }
 
-// blocks per CU (= waves per SIMD): C = 16 -> 3 (168 registers), but 2 for the variant that carries the BatchNorm prologue AND the effgrad
-// operand at the same resolution (its prefetch registers spill at 168); C = 32 -> 2 (76 KB of LDS)
+// blocks per CU (= waves per SIMD): C = 16 -> 3 (168 registers), but 2 for the generator's variants, which carry the BatchNorm prologue AND the
+// effgrad operand (their prefetch registers spill at 168); C = 32 -> 2 (76 KB of LDS)
 template <int C, bool AFF, int RS, bool EFF>
-__host__ __device__ constexpr int b3_occ() { return C == 16 ? ((AFF && EFF && RS == 0) ? 2 : 3) : 2; }
+__host__ __device__ constexpr int b3_occ() { return C == 16 ? ((AFF && EFF) ? 2 : 3) : 2; }
 
 template <int C, bool AFF, int RS, bool EFF>
 __global__ __launch_bounds__(256, (b3_occ<C, AFF, RS, EFF>())) void conv3x3_bwd_kernel(Bwd3Args a, int tiles_w, int tpi, int tpb, int bpi, int nblk) {
@@ -467,11 +467,13 @@ struct B3Plan {
 static bool b3_shape_ok(int C, int rs, bool aff, bool relu) { return (C == 16 || C == 32) && (rs == 0 || rs == 1) && relu; }
 // C = 32 with BatchNorm prologue + effgrad at the same resolution: 16 prefetched chunks per thread next to 76 accumulator registers spill at
 // the 256-register cap of two blocks per CU and the launch then loses to the separate ones (322 vs 297 us at 128x384, N = 40): not offered
-static bool b3_variant_ok(int C, int rs, bool aff, bool eff) { return !(C == 32 && rs == 0 && aff && eff); }
+// Only the combinations the networks have are instantiated: the discriminator's layers (bare ReLU, no BatchNorm behind them) and the
+// generator's (BatchNorm prologue + effgrad).
+static bool b3_variant_ok(int C, int rs, bool aff, bool eff) { return aff == eff && !(C == 32 && rs == 0 && aff && eff); }
 
 static int b3_plan(const Bwd3Args& a, B3Plan& p) {
     CHECK_ARG(b3_shape_ok(a.C, a.src.rs, a.src.scale != nullptr, a.src.relu != 0), "conv3x3_bwd: C = %d, rs %d, relu %d is not instantiated", a.C, a.src.rs, a.src.relu);
-    CHECK_ARG(b3_variant_ok(a.C, a.src.rs, a.src.scale != nullptr, a.y != nullptr), "conv3x3_bwd: C = 32 with affine prologue + effgrad at the same resolution is not offered");
+    CHECK_ARG(b3_variant_ok(a.C, a.src.rs, a.src.scale != nullptr, a.y != nullptr), "conv3x3_bwd: this (C, rs, affine prologue, effgrad) combination is not instantiated");
     CHECK_ARG(a.H % B3_TH == 0 && a.W % B3_TW == 0, "conv3x3_bwd: H %% 8 == 0 and W %% 32 == 0 required (%d x %d)", a.H, a.W);
     if (a.src.rs == 0) CHECK_ARG(a.H == a.src.Hs && a.W == a.src.Ws, "conv3x3_bwd: geometry mismatch");
     if (a.src.rs == 1) CHECK_ARG(a.H == 2 * a.src.Hs && a.W == 2 * a.src.Ws, "conv3x3_bwd: upsample geometry mismatch");
@@ -486,7 +488,7 @@ static int b3_plan(const Bwd3Args& a, B3Plan& p) {
     p.tiles_w = a.W / B3_TW;
     p.tpi = p.tiles_w * (a.H / B3_TH);
     // ONE round of persistent blocks: whole blocks per image
-    const int occ = a.C == 16 ? ((a.src.scale != nullptr && a.y != nullptr && a.src.rs == 0) ? 2 : 3) : 2;      // == b3_occ of the variant
+    const int occ = a.C == 16 ? ((a.src.scale != nullptr && a.y != nullptr) ? 2 : 3) : 2;      // == b3_occ of the variant
     const int slots = 256 * occ;
     int bpi = slots / a.N;
     if (bpi < 1) bpi = 1;
@@ -544,11 +546,13 @@ static int b3_go(const Bwd3Args& a, const B3Plan& p, hipStream_t st) {
 
 template <int C, int RS>
 static int b3_dispatch(const Bwd3Args& a, const B3Plan& p, hipStream_t st) {
-    const bool aff = a.src.scale != nullptr, eff = a.y != nullptr;
-    if (aff && eff) return b3_go<C, true, RS, true>(a, p, st);
-    if (aff) return b3_go<C, true, RS, false>(a, p, st);
-    if (eff) return b3_go<C, false, RS, true>(a, p, st);
-    return b3_go<C, false, RS, false>(a, p, st);
+    const bool aff = a.src.scale != nullptr;            // == (a.y != nullptr): b3_variant_ok
+    if constexpr (C == 32 && RS == 0) {
+        return b3_go<C, false, RS, false>(a, p, st);    // (the BatchNorm + effgrad form of this shape is not offered)
+    } else {
+        if (aff) return b3_go<C, true, RS, true>(a, p, st);
+        return b3_go<C, false, RS, false>(a, p, st);
+    }
 }
 
 extern "C" int ieagan_conv3x3_bwd(const ieagan_conv3x3_bwd_desc* d, void* stream) {

@@ -170,7 +170,7 @@ class Attention(nn.Module):
         the 2x2 max-pool of phi / g and the final gamma*o + x are two small HIP element-wise kernels."""
         N, Hh, Ww, C = xa.shape
         # xa feeds theta, phi, g and the residual: their four gradients are summed inside the dgrad kernels (ops.SumLink)
-        link = ops.SumLink(4) if (torch.is_grad_enabled() and xa.requires_grad and ops.FUSE_SHORTCUT_GRAD) else None
+        link = ops.SumLink(4) if (torch.is_grad_enabled() and xa.requires_grad and ops.opts_of(recs[prefix + ".theta"]).fuse_shortcut_grad) else None
         theta, _ = self.theta.fused(xa, recs[prefix + ".theta"], res_in=link)
         phi, _ = self.phi.fused(xa, recs[prefix + ".phi"], res_in=link)
         g, _ = self.g.fused(xa, recs[prefix + ".g"], res_in=link)

@@ -127,7 +127,7 @@ class GBlock(nn.Module):
         cnt = (N // events) * Hh * Ww
         tr = self.training
         E = events
-        link = ops.ResLink() if (torch.is_grad_enabled() and ops.FUSE_SHORTCUT_GRAD) else None   # conv4 -> conv1, in-kernel
+        link = ops.ResLink() if (torch.is_grad_enabled() and ops.opts_of(recs[prefix + ".conv1"]).fuse_shortcut_grad) else None   # conv4 -> conv1, in-kernel
         s, t = self.bn1.scale_shift(xstats, bank, *cols["bn1"], cnt, E)
         h, st = self.conv1.fused(xa, recs[prefix + ".conv1"], scale=s, shift=t, relu=True, want_stats=tr, res_in=link, events=E)
         s, t = self.bn2.scale_shift(st, bank, *cols["bn2"], cnt, E)
@@ -312,14 +312,14 @@ class DBlock(nn.Module):
         """Can ``ops.DStemFn`` take input_conv + this block's conv1 / conv_sc / pooled shortcut?  (the first block of the shipped
         ch = 32 discriminator on a map whose height / width are multiples of 8 / 64: the stem's backward runs conv_sc through the fused
         1x1 backward at the POOLED resolution, whose tiles need (W / 2) % 32 == 0)"""
-        return (ops.FUSE_D_STEM and x.is_cuda and x.dim() == 4 and x.shape[1] == 1 and x.shape[2] % 8 == 0 and x.shape[3] % 64 == 0
+        return (x.is_cuda and x.dim() == 4 and x.shape[1] == 1 and x.shape[2] % 8 == 0 and x.shape[3] % 64 == 0
                 and input_conv.out_channels == 32 and self.in_channels == 32 and self.out_channels == 64 and self.hidden_channels == 16
                 and self.downsample is not None and not self.preactivation and self.learnable_sc
                 and all(c.bias is not None for c in (input_conv, self.conv1, self.conv_sc)))
 
     def fused_stem(self, x, input_conv, recs, prefix):
         """The block with its input side fused into one launch (ops.DStemFn): x is the fp32 image [N, 1, H, W]."""
-        link = ops.ResLink() if (torch.is_grad_enabled() and ops.FUSE_SHORTCUT_GRAD) else None    # conv4 -> stem backward
+        link = ops.ResLink() if (torch.is_grad_enabled() and ops.opts_of(recs[prefix + ".conv1"]).fuse_shortcut_grad) else None    # conv4 -> stem backward
         h, p0, sc = ops.DStemFn.apply(x, input_conv.weight, input_conv.bias, self.conv1.weight, self.conv1.bias, self.conv_sc.weight,
                                       self.conv_sc.bias, recs["input_conv"], recs[prefix + ".conv1"], recs[prefix + ".conv_sc"], link)
         h, _ = self.conv2.fused(h, recs[prefix + ".conv2"], relu=True)
@@ -329,7 +329,7 @@ class DBlock(nn.Module):
 
     def fused(self, xa, recs, prefix):
         rs = 2 if self.downsample else 0
-        link = ops.ResLink() if (torch.is_grad_enabled() and ops.FUSE_SHORTCUT_GRAD) else None   # conv4 (-> conv_sc) -> conv1
+        link = ops.ResLink() if (torch.is_grad_enabled() and ops.opts_of(recs[prefix + ".conv1"]).fuse_shortcut_grad) else None   # conv4 (-> conv_sc) -> conv1
         h, _ = self.conv1.fused(xa, recs[prefix + ".conv1"], relu=self.preactivation, res_in=link)
         h, _ = self.conv2.fused(h, recs[prefix + ".conv2"], relu=True)
         h, _ = self.conv3.fused(h, recs[prefix + ".conv3"], relu=True)
@@ -431,7 +431,7 @@ class Discriminator(nn.Module):
         plan = self._prepare()
         recs = plan["bank"].run(self.training, self.SN_eps)
         first = self.blocks[0][0]
-        stem = isinstance(first, DBlock) and first.stem_ok(self.input_conv, x)
+        stem = plan["bank"].opts.fuse_d_stem and isinstance(first, DBlock) and first.stem_ok(self.input_conv, x)
         if stem:            # input_conv + the first block's three reads of its output: one launch (h0 never reaches HBM)
             h = first.fused_stem(x, self.input_conv, recs, "blocks.0.0")
         else:

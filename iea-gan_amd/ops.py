@@ -96,6 +96,66 @@ class direct_grads:
 
 
 # =====================================================================================================
+# Execution options: which of the equivalent launch sequences the passes of ONE network use
+# =====================================================================================================
+class ExecOptions:
+    """Launch-orchestration choices of one network -- properties of the network like ``conv_dtype`` (whose IEAGAN_CONV_FP8 bit rides in the
+    descriptor of its layers), not process-wide switches: every ``SNBank`` (one per network) carries its own copy, seeded from ``DEFAULTS``
+    when the bank is built; the autograd shells read them through ``opts_of(rec)``.  Tests and benchmarks change the options of the
+    network they measure (``set_options(net, ...)``) -- e.g. bench.py serialises the weight gradients of its per-kernel timing pass
+    without touching any other network of the process.
+
+    wgrad_side_stream   weight-gradient launches of a training backward pass on a side stream (nothing in the pass reads dW before the
+                        batched spectral-norm backward at its end, ``SNPass.flush`` joins)
+    two_stage_wgrad     conv_wgrad: partial slabs + reduction launch instead of float atomics when the atomic volume is large
+    use_tr_read         ds_read_b64_tr_b16 operand reads in conv_wgrad (False: scalar LDS reads, the test reference)
+    fuse_bn_backward    BatchNorm-apply backward inside the dgrad epilogue (False: the stand-alone prologue_bwd pass)
+    fuse_shortcut_grad  residual-shortcut gradients added inside the dx-producing kernel (False: autograd adds)
+    fuse_1x1_backward / fuse_3x3_backward (+ *_min_pixels)   the whole-backward kernels conv1x1_bwd / conv3x3_bwd (False: separate launches)
+    fuse_d_stem         D.input_conv + the first DBlock's conv1 / conv_sc / pooled shortcut in one launch each way
+    b1_flags            ieagan_conv1x1_bwd_desc.flags (benchmarks: H.B1_OCC2 / H.B1_OCC3)"""
+    FIELDS = dict(wgrad_side_stream=True, two_stage_wgrad=True, use_tr_read=True, fuse_bn_backward=True, fuse_shortcut_grad=True,
+                  fuse_1x1_backward=True, fuse_1x1_min_pixels=1 << 16, fuse_3x3_backward=True, fuse_3x3_min_pixels=1 << 16,
+                  fuse_d_stem=True, b1_flags=0)
+    __slots__ = tuple(FIELDS)
+
+    def __init__(self, like=None, **kw):
+        src = like if like is not None else globals().get("DEFAULTS")
+        for k, v in self.FIELDS.items():
+            setattr(self, k, getattr(src, k) if src is not None else v)
+        self.update(**kw)
+
+    def update(self, **kw):
+        for k, v in kw.items():
+            if k not in self.FIELDS:
+                raise KeyError(f"unknown execution option {k!r} (have: {sorted(self.FIELDS)})")
+            setattr(self, k, v)
+        return self
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k in self.FIELDS}
+
+
+DEFAULTS = ExecOptions()          # seeds the options of every bank built from now on (tests: change, build, restore)
+
+
+def opts_of(rec) -> "ExecOptions":
+    """Options of the network the layer record ``rec`` belongs to (records without a bank -- identity convs -- take the defaults)."""
+    ps = getattr(rec, "pass_", None)
+    return ps.bank.opts if ps is not None else DEFAULTS
+
+
+def opts_of_net(net) -> "ExecOptions":
+    return (net if isinstance(net, SNBank) else net._prepare()["bank"]).opts
+
+
+def set_options(net, **kw) -> "ExecOptions":
+    """Change execution options of ONE network (a Generator / Discriminator, or anything with ``_prepare()``) or of a bank."""
+    bank = net if isinstance(net, SNBank) else net._prepare()["bank"]
+    return bank.opts.update(**kw)
+
+
+# =====================================================================================================
 # Spectral-norm bank: every SN layer of a network in three launches per forward
 # =====================================================================================================
 KIND_PLAIN, KIND_CONV, KIND_C1_IN, KIND_C1_OUT = 0, 1, 2, 3
@@ -183,6 +243,7 @@ class SNBank:
 
     def __init__(self, arena: torch.Tensor, entries, stack=(), owner=None, biases=None):
         self.arena = arena
+        self.opts = ExecOptions()               # this network's execution options (a copy of DEFAULTS as of now)
         self._prefetched = []
         self.owner, self.bwd = owner, None          # owner: the network's Arena (flat gradient buffer) -> batched backward
         self.names = [e[0] for e in entries]
@@ -415,6 +476,12 @@ class StackedSNLinearFn(torch.autograd.Function):
 # =====================================================================================================
 # BatchNorm finalize: statistics -> per-(n,c) scale / shift
 # =====================================================================================================
+def _fin_scratch(which, *args, device):
+    """Zeroed hand-off space of a bn_finalize launch that splits its fold over several workgroups (None: not needed)."""
+    n = getattr(H.lib(), "ieagan_bn_finalize_" + which + "_scratch")(*args)
+    return zeros((n,), device) if n > 0 else None
+
+
 class GainBank:
     """The [N, sum C] matrix of all ccbn gains/biases of one generator forward, plus the shared
     gradient buffer its consumers write into (each BN owns disjoint columns; the last consumer to
@@ -444,7 +511,8 @@ class BNFinalizeFn(torch.autograd.Function):
         repl = int(stats.shape[1]) if stats is not None else 0
         H.call("ieagan_bn_finalize_fwd", H.ptr(stats), float(count), gb.data_ptr() + 4 * col_gain,
                gb.data_ptr() + 4 * col_bias, ld, 1, float(eps), float(momentum), int(training), run_mean.data_ptr(),
-               run_var.data_ptr(), scale.data_ptr(), shift.data_ptr(), mr.data_ptr(), N, C, events, repl, H.stream())
+               run_var.data_ptr(), scale.data_ptr(), shift.data_ptr(), mr.data_ptr(), N, C, events, repl,
+               H.ptr(_fin_scratch("fwd", C, events, repl, device=dev) if training else None), H.stream())
         ctx.bank, ctx.cols, ctx.C, ctx.count, ctx.training, ctx.events, ctx.repl = bank, (col_gain, col_bias), C, count, training, events, repl
         ctx.has_stats = stats is not None
         ctx.save_for_backward(gb, mr)
@@ -469,7 +537,8 @@ class BNFinalizeFn(torch.autograd.Function):
             dshift = dshift.contiguous() if dshift is not None else torch.zeros(N, C, device=gb.device)
         H.call("ieagan_bn_finalize_bwd", dscale.data_ptr(), dshift.data_ptr(), gb.data_ptr() + 4 * ctx.cols[0], ld, 1,
                mr.data_ptr(), float(ctx.count), int(ctx.training), gbuf.data_ptr() + 4 * ctx.cols[0],
-               gbuf.data_ptr() + 4 * ctx.cols[1], ld, dstat.data_ptr(), N, C, E, repl, H.stream())
+               gbuf.data_ptr() + 4 * ctx.cols[1], ld, dstat.data_ptr(), N, C, E, repl,
+               H.ptr(_fin_scratch("bwd", N, C, E, repl, device=gb.device)), H.stream())
         bank.pending -= 1
         dgb = gbuf if bank.pending == 0 else None
         dstats = dstat.unsqueeze(1).expand(E, ctx.repl, 2, C) if (ctx.has_stats and ctx.training) else None
@@ -493,7 +562,8 @@ class BNFinalizePlainFn(torch.autograd.Function):
         repl = int(stats.shape[1]) if stats is not None else 0
         H.call("ieagan_bn_finalize_fwd", H.ptr(stats), float(count), gain.data_ptr(), bias.data_ptr(), 0, 0, float(eps),
                float(momentum), int(training), run_mean.data_ptr(), run_var.data_ptr(), scale.data_ptr(),
-               shift.data_ptr(), mr.data_ptr(), rows, C, events, repl, H.stream())
+               shift.data_ptr(), mr.data_ptr(), rows, C, events, repl,
+               H.ptr(_fin_scratch("fwd", C, events, repl, device=dev) if training else None), H.stream())
         ctx.count, ctx.training, ctx.has_stats, ctx.events, ctx.rows, ctx.repl = count, training, stats is not None, events, rows, repl
         ctx.save_for_backward(gain, mr)
         return scale, shift
@@ -511,7 +581,7 @@ class BNFinalizePlainFn(torch.autograd.Function):
         dshift = dshift.contiguous() if dshift is not None else torch.zeros(shape, device=dev)
         H.call("ieagan_bn_finalize_bwd", dscale.data_ptr(), dshift.data_ptr(), gain.data_ptr(), 0, 0, mr.data_ptr(),
                float(ctx.count), int(ctx.training), dgain.data_ptr(), dbias.data_ptr(), 0, dstat.data_ptr(), rows, C, E, 0,
-               H.stream())
+               None, H.stream())
         dstats = dstat.unsqueeze(1).expand(E, ctx.repl, 2, C) if (ctx.has_stats and ctx.training) else None
         return dstats, dgain, dbias, None, None, None, None, None, None, None, None
 
@@ -543,12 +613,9 @@ def _conv_launch(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu, N, Hc, Wc, Cin,
     return stats
 
 
-USE_TR_READ = True        # ds_read_b64_tr_b16 operand reads in conv_wgrad (False: scalar LDS reads)
-TWO_STAGE_WGRAD = True    # conv_wgrad: partial slabs + reduction launch instead of float atomics when the atomic volume is large
-# Weight-gradient launches of a training backward pass go to a side stream: nothing in the pass reads dW before the batched
-# spectral-norm backward at its end (SNPass.flush joins), so they run under the dgrad chain of this and the following layers --
-# the mid / small feature maps (<= 240 blocks on 256 CUs, long float-atomic tails) leave most of the chip idle on their own.
-WGRAD_SIDE_STREAM = True
+# Weight-gradient launches of a training backward pass go to a side stream (ExecOptions.wgrad_side_stream): nothing in the pass reads dW
+# before the batched spectral-norm backward at its end (SNPass.flush joins), so they run under the dgrad chain of this and the following
+# layers -- the mid / small feature maps (<= 240 blocks on 256 CUs, long float-atomic tails) leave most of the chip idle on their own.
 _WGRAD_STREAMS = {}
 
 
@@ -568,9 +635,6 @@ def release_device_caches():
     _PLACEHOLDERS.clear()
 
 
-FUSE_BN_BACKWARD = True   # BatchNorm-apply backward inside the dgrad epilogue (False: the stand-alone prologue_bwd pass)
-
-
 class BNLink:
     """Side channel between a conv's backward and the backward of the BatchNorm finalize that produced its prologue scale /
     shift: when the dgrad kernel folds the BatchNorm-apply backward in, the per-image sums (d shift, d scale) arrive as replicated
@@ -579,9 +643,6 @@ class BNLink:
 
     def __init__(self):
         self.acc = None
-
-FUSE_SHORTCUT_GRAD = True # add residual-shortcut gradients inside the dx-producing kernel (False: autograd adds)
-
 
 class ResLink:
     """Hand-off of a shortcut gradient between two convs of one residual block.
@@ -639,25 +700,23 @@ def _placeholder(like):
 
 
 # The whole backward of a 1x1 convolution on a large map in ONE launch (csrc/conv1x1_bwd.hip): effgrad + dgrad + prologue backward +
-# wgrad + bias column sums, every operand tile read once.  False: the separate launches (tests compare the two).
-FUSE_1X1_BACKWARD = True
-FUSE_1X1_MIN_PIXELS = 1 << 16
-FUSE_1X1_FLAGS = 0              # benchmarks only: H.B1_OCC2 / H.B1_OCC3
+# wgrad + bias column sums, every operand tile read once (ExecOptions.fuse_1x1_backward; tests compare it with the separate launches).
 
 
 def _fused_1x1_eligible(ctx, dout, dstats):
     """Can ``ConvFn.backward`` take the fused 1x1 backward for this node?  (shape instantiated, big map, both gradients wanted, a
     shortcut-gradient link the kernel can add in place.)"""
-    if not FUSE_1X1_BACKWARD:
+    rec = ctx.rec
+    o = opts_of(rec)
+    if not o.fuse_1x1_backward:
         return False
     taps, rs, relu, Ca, ra_rs, nstride, Hc, Wc = ctx.cfg
-    rec = ctx.rec
     need = ctx.needs_input_grad
     has_bias, has_aff, has_ra, has_rb = ctx.has
     res_out, res_in = ctx.links
     x = ctx.saved_tensors[0]
     N = x.shape[0]
-    if taps != 1 or rs not in (0, 2) or not need[0] or not need[1] or Wc % 32 != 0 or N * Hc * Wc < FUSE_1X1_MIN_PIXELS:
+    if taps != 1 or rs not in (0, 2) or not need[0] or not need[1] or Wc % 32 != 0 or N * Hc * Wc < o.fuse_1x1_min_pixels:
         return False
     if not H.lib().ieagan_conv1x1_bwd_supported(rec.cin, rec.out, rs, int(has_aff)):
         return False
@@ -709,7 +768,7 @@ def _conv1x1_backward_fused(ctx, dout, dstats):
     d = H.Conv1x1BwdDesc(N, Hc, Wc, Cin, Cout, rec.kpad, rec.kpad2, H.src_desc(x, Cx, Hs, Ws, rs, scale, shift, nstride, relu),
                          g.data_ptr(), Cg, H.ptr(out) if eff else None, H.ptr(dstat), N // ctx.events, H.ptr(geff), rec.w_bwd.data_ptr(),
                          H.ptr(lg), lC or 0, lCa or 0, lmode or 0, dx.data_ptr(), out_mode, 16 if has_aff else None, dwp.data_ptr(), None, H.ptr(colsum),
-                         FUSE_1X1_FLAGS, 0)
+                         opts_of(rec).b1_flags, 0)
     acc = None
     if has_aff:         # per-image BatchNorm accumulators: one slot per block of the image (single adder: bit-reproducible)
         d.bn_slots = H.lib().ieagan_conv1x1_bwd_slots(d)
@@ -761,16 +820,13 @@ def _conv1x1_backward_fused(ctx, dout, dstats):
 
 # The whole backward of a 3x3 convolution with Cin = Cout = 16 / 32 on a large map in ONE launch (csrc/conv3x3_bwd.hip): effgrad on load + dgrad
 # with the prologue backward (ReLU mask / BatchNorm apply / 2x2 sum of an up-sampled source) in its store phase + wgrad + bias column sums
-# from the same LDS tiles.  False: the separate launches (tests compare the two).
-FUSE_3X3_BACKWARD = True
-FUSE_3X3_MIN_PIXELS = 1 << 16
-
-
+# from the same LDS tiles (ExecOptions.fuse_3x3_backward; tests compare it with the separate launches).
 def _fused_3x3_eligible(ctx, dout, dstats):
-    if not FUSE_3X3_BACKWARD:
+    rec = ctx.rec
+    o = opts_of(rec)
+    if not o.fuse_3x3_backward:
         return False
     taps, rs, relu, Ca, ra_rs, nstride, Hc, Wc = ctx.cfg
-    rec = ctx.rec
     need = ctx.needs_input_grad
     has_bias, has_aff, has_ra, has_rb = ctx.has
     res_out, res_in = ctx.links
@@ -778,7 +834,7 @@ def _fused_3x3_eligible(ctx, dout, dstats):
     N = x.shape[0]
     if taps != 9 or rec.cin != rec.out or not need[0] or not need[1] or has_ra or has_rb or res_out is not None or res_in is not None:
         return False
-    if N * Hc * Wc < FUSE_3X3_MIN_PIXELS or rec.kpad != rec.kpad2 or x.shape[3] != rec.cin:
+    if N * Hc * Wc < o.fuse_3x3_min_pixels or rec.kpad != rec.kpad2 or x.shape[3] != rec.cin:
         return False
     if not H.lib().ieagan_conv3x3_bwd_supported(rec.cin, rs, int(has_aff), int(bool(relu)), int(dstats is not None), Hc, Wc):
         return False
@@ -865,6 +921,7 @@ class ConvFn(torch.autograd.Function):
             return _conv3x3_backward_fused(ctx, dout, dstats)
         x, weight, scale, shift, out = ctx.saved_tensors
         rec = ctx.rec
+        opts = opts_of(rec)
         taps, rs, relu, Ca, ra_rs, nstride, Hc, Wc = ctx.cfg
         has_bias, has_aff, has_ra, has_rb = ctx.has
         res_out, res_in = ctx.links
@@ -922,7 +979,7 @@ class ConvFn(torch.autograd.Function):
         dwp = fork = None
         if need[1]:
             dwp = sn_scratch(rec, "w", (Cout, rec.kpad), dev)
-            if (WGRAD_SIDE_STREAM and rec.deferred and d_ra is not g and d_rb is None):
+            if (opts.wgrad_side_stream and rec.deferred and d_ra is not g and d_rb is None):
                 fork = torch.cuda.Event()
                 fork.record(torch.cuda.current_stream())
         # ---- data gradient
@@ -938,7 +995,7 @@ class ConvFn(torch.autograd.Function):
             if res_in is not None:
                 lg, lC, lCa, lmode = res_in.take()
             bn_link = getattr(scale, "_bn_link", None) if has_aff else None
-            if (FUSE_BN_BACKWARD and has_aff and rs == 0 and bn_link is not None and (Hs * Ws) % 128 == 0 and Cin % 8 == 0
+            if (opts.fuse_bn_backward and has_aff and rs == 0 and bn_link is not None and (Hs * Ws) % 128 == 0 and Cin % 8 == 0
                     and (res_in is None or lmode in (0, 1))):
                 # BatchNorm apply + ReLU backward inside the dgrad epilogue: dx is written directly, the per-(n, c) sums go to
                 # replicated per-image accumulators that bn_finalize_bwd folds (no da tensor, no stand-alone pass over da / x)
@@ -1004,11 +1061,11 @@ class ConvFn(torch.autograd.Function):
             def launch():
                 # large weight x many pixel splits: the blocks store partial slabs and a second launch folds them (two-stage
                 # accumulation; the float-atomic tail was the longest phase of these launches)
-                ws_n = H.lib().ieagan_conv_wgrad_workspace(d, int(USE_TR_READ)) if TWO_STAGE_WGRAD else 0
+                ws_n = H.lib().ieagan_conv_wgrad_workspace(d, int(opts.use_tr_read)) if opts.two_stage_wgrad else 0
                 if ws_n > 0:
                     ws = torch.empty(ws_n, dtype=torch.float32, device=dev)
                     d.partials = ws.data_ptr()
-                H.call("ieagan_conv_wgrad", d, int(USE_TR_READ), H.stream())
+                H.call("ieagan_conv_wgrad", d, int(opts.use_tr_read), H.stream())
 
             if fork is not None:
                 side = wgrad_stream(dev)
@@ -1079,9 +1136,6 @@ class InputConvFn(torch.autograd.Function):
         return dimg, dW, dbias, None
 
 
-FUSE_D_STEM = True          # D.input_conv + the first DBlock's conv1 / conv_sc / pooled shortcut in one launch each way (csrc/d_stem.hip)
-
-
 class DStemFn(torch.autograd.Function):
     """Input side of the first discriminator block: img -> (h1 = conv1(h0), p0 = AvgPool2d(h0), sc = conv_sc(p0)) with
     h0 = input_conv(img) recomputed on chip (reference model.py:905 + 534-557).  ``link``: the ResLink the block's conv4 deposits its
@@ -1128,7 +1182,7 @@ class DStemFn(torch.autograd.Function):
             colsum = sn_scratch(recsc, "b", (STAT_REPL, 32), dev)
             d = H.Conv1x1BwdDesc(N, Hp, Wp, 32, 32, recsc.kpad, recsc.kpad2, H.src_desc(p0, 32, Hp, Wp, 0, None, None, 0, False), dsc.data_ptr(), Cg,
                                  None, None, N, None, recsc.w_bwd.data_ptr(), H.ptr(lg), lC if lg is not None else 0, lCa if lg is not None else 0, 0,
-                                 dpt.data_ptr(), 1, None, dwp.data_ptr(), None, colsum.data_ptr(), FUSE_1X1_FLAGS, 0)
+                                 dpt.data_ptr(), 1, None, dwp.data_ptr(), None, colsum.data_ptr(), opts_of(recsc).b1_flags, 0)
             ws_n = H.lib().ieagan_conv1x1_bwd_workspace(d)
             if ws_n > 0:
                 ws = torch.empty(ws_n, dtype=torch.float32, device=dev)

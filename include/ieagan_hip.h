@@ -215,12 +215,18 @@ int ieagan_prologue_bwd(const void* da, const void* x, int Cx, const float* scal
 int ieagan_bn_finalize_fwd(const float* stats, float count, const float* gain, const float* bias, int ld,
                            int plus_one, float eps, float momentum, int training, float* run_mean,
                            float* run_var, float* scale, float* shift, float* mean_rstd, int N, int C, int E,
-                           int repl, void* stream);
+                           int repl, float* scratch, void* stream);
+/* `scratch`: ieagan_bn_finalize_fwd_scratch(C, E, repl) caller-ZEROED floats (0: none needed), or NULL.  With many slots the fold is split
+ * over several workgroups which hand their partial sums over through it (ticket of the last arriver); without it one workgroup per 32
+ * channels folds all the slots (same result bit for bit, slower for repl > 128). */
+long ieagan_bn_finalize_fwd_scratch(int C, int E, int repl);
 /* acc_repl > 0: dshift is ignored and dscale points at the replicated per-image accumulators [rows][acc_repl][2][C]
  * ({sum d, sum d*x}) a BatchNorm-backward dgrad launch produced (ieagan_conv_desc.bnb_*); they are folded here. */
 int ieagan_bn_finalize_bwd(const float* dscale, const float* dshift, const float* gain, int ld, int plus_one,
                            const float* mean_rstd, float count, int training, float* dgain, float* dbias,
-                           int ldd, float* dstat, int N, int C, int E, int acc_repl, void* stream);
+                           int ldd, float* dstat, int N, int C, int E, int acc_repl, float* scratch, void* stream);
+/* `scratch`: ieagan_bn_finalize_bwd_scratch(N, C, E, acc_repl) caller-ZEROED floats (0: none needed), or NULL (one workgroup per 32 channels). */
+long ieagan_bn_finalize_bwd_scratch(int N, int C, int E, int acc_repl);
 int ieagan_res_bwd(const void* g, int Cg, void* dr, int Cr, int Ca, int mode, int N, int Hr, int Wr, void* stream);
 /* stats (optional): fp32 [E][S][2][C] caller-zeroed (sum, sumsq) slots per event, E = N / n_per_event (0: one event),
  * S = (N / E) * ceil(HW / 32): one slot per (image of the event, 32-pixel block) -- a single adder each, bit-reproducible */

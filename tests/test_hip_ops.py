@@ -550,7 +550,7 @@ def test_bn_backward_fused_into_dgrad(dev, taps, C, Cout, Hh, Ww, N, res):
         sg = r16(torch.randn(N, C, 2 * Hh, 2 * Ww, device=dev))
 
     def hip(fused):
-        ops.FUSE_BN_BACKWARD = fused
+        ops.DEFAULTS.fuse_bn_backward = fused          # (seeds the bank make_rec builds below)
         try:
             rec, Wv, _, _ = make_rec(W.clone(), u.clone(), torch.ones(1, device=dev))
             x2, gb2 = x.clone().requires_grad_(True), gb.clone().requires_grad_(True)
@@ -568,7 +568,7 @@ def test_bn_backward_fused_into_dgrad(dev, taps, C, Cout, Hh, Ww, N, res):
             gx, ggb = torch.autograd.grad((out.float() * nhwc(go).float()).sum(), [x2, gb2])
             return nchw(out), gx, ggb
         finally:
-            ops.FUSE_BN_BACKWARD = True
+            ops.DEFAULTS.fuse_bn_backward = True
 
     o1, gx1, gg1 = hip(True)
     o0, gx0, gg0 = hip(False)
@@ -847,11 +847,11 @@ def test_fused_1x1_backward_matches_separate_launches(dev, ref_cfg, kind, cin, c
     yv0 = torch.randn(N, 256, device=dev)
     go = None
     res = {}
-    keep = ops.FUSE_1X1_BACKWARD, ops.FUSE_1X1_MIN_PIXELS
+    keep = ops.DEFAULTS.fuse_1x1_backward, ops.DEFAULTS.fuse_1x1_min_pixels
     launches = {}
     try:
         for fused in (False, True):
-            ops.FUSE_1X1_BACKWARD, ops.FUSE_1X1_MIN_PIXELS = fused, 1024
+            ops.DEFAULTS.fuse_1x1_backward, ops.DEFAULTS.fuse_1x1_min_pixels = fused, 1024      # (seed the bank of the block built below)
             blk = build()
             x = x0.clone().requires_grad_(True)
             yv = yv0.clone().requires_grad_(True)
@@ -870,7 +870,7 @@ def test_fused_1x1_backward_matches_separate_launches(dev, ref_cfg, kind, cin, c
             launches[fused] = {r["name"]: r["launches"] for r in _hip.prof_collect()}
             res[fused] = (y.detach(), dict(zip(["x"] + (["yv"] if kind == "g" else []) + names, grads)))
     finally:
-        ops.FUSE_1X1_BACKWARD, ops.FUSE_1X1_MIN_PIXELS = keep
+        ops.DEFAULTS.fuse_1x1_backward, ops.DEFAULTS.fuse_1x1_min_pixels = keep
     assert launches[True].get("conv1x1_bwd", 0) >= 1 and "conv1x1_bwd" not in launches[False], launches
     assert launches[True].get("conv1x1_wgrad", 0) < launches[False].get("conv1x1_wgrad", 0), launches
     # (the two forwards differ only through the float-atomic order of the BatchNorm statistics: last-bit bf16 flips)
@@ -913,10 +913,10 @@ def test_fused_3x3_backward_matches_separate_launches(dev, C, Hs, Ws, aff, rs, s
     go = nhwc(torch.randn(N, C, Hc, Wc, device=dev))
     dsum = 0.05 * torch.randn(events, 1, 2, C, device=dev)
     res, launches = {}, {}
-    keep = ops.FUSE_3X3_BACKWARD, ops.FUSE_3X3_MIN_PIXELS
+    keep = ops.DEFAULTS.fuse_3x3_backward, ops.DEFAULTS.fuse_3x3_min_pixels
     try:
         for fused in (False, True):
-            ops.FUSE_3X3_BACKWARD, ops.FUSE_3X3_MIN_PIXELS = fused, 1024
+            ops.DEFAULTS.fuse_3x3_backward, ops.DEFAULTS.fuse_3x3_min_pixels = fused, 1024      # (seed the bank make_rec builds below)
             rec, Wv, uv, svv = make_rec(W0.clone(), u.clone(), torch.ones(1, device=dev))
             Wp = Wv.detach().requires_grad_(True)
             xa = x0.clone().requires_grad_(True)
@@ -936,7 +936,7 @@ def test_fused_3x3_backward_matches_separate_launches(dev, C, Hs, Ws, aff, rs, s
             launches[fused] = {r["name"]: r["launches"] for r in _hip.prof_collect()}
             res[fused] = dict(zip([n for n, t in zip(("x", "W", "bias", "scale", "shift"), (xa, Wp, b2, sc2, sh2)) if t is not None], grads))
     finally:
-        ops.FUSE_3X3_BACKWARD, ops.FUSE_3X3_MIN_PIXELS = keep
+        ops.DEFAULTS.fuse_3x3_backward, ops.DEFAULTS.fuse_3x3_min_pixels = keep
     assert launches[True].get("conv3x3_bwd", 0) == 1 and "conv3x3_bwd" not in launches[False], launches
     assert "conv3x3_wgrad" not in launches[True] and "effgrad" not in launches[True] and "prologue_bwd" not in launches[True], launches
     for k, ref in res[False].items():

@@ -348,3 +348,34 @@ def test_integration_doc_stub_matches_the_binding():
         assert m, cls
         names = re.findall(r'\("(\w+)"', m.group(1))
         assert names == [f[0] for f in ref._fields_], (cls, names)
+
+
+def test_register_spill_ratchet_of_the_built_library():
+    """Scratch (register spills) per kernel family, read from the code-object metadata of the built library (tools/codeobj_notes.py, no GPU
+    needed).  Two statements: (1) every instantiated variant of the round-4 kernel conv3x3_bwd is spill-free -- its two occupancy
+    classes and the variant it does NOT offer (C = 32 with BatchNorm prologue + effgrad at the same resolution) exist for exactly that
+    reason; (2) no OTHER family grows: the counts below are the state of this round (most are variants the step never launches; the
+    launched ones are listed in DESIGN section 3), a new spill or a larger one fails here instead of showing up as a slower step."""
+    import collections
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import codeobj_notes as cn
+    so = os.path.join(root, "iea-gan_amd", "libieagan_hip.so")
+    if not os.path.exists(so):
+        pytest.skip("library not built")
+    rows = cn.kernels(so)
+    names = cn.demangle([r["name"] for r in rows])
+    assert len(rows) > 500, len(rows)
+    fam = collections.defaultdict(lambda: [0, 0])        # family -> [kernels with scratch, largest scratch in bytes / lane]
+    for r, n in zip(rows, names):
+        f = re.sub(r"^void ", "", n).split("<")[0].split("(")[0]
+        if r["scratch"]:
+            fam[f][0] += 1
+            fam[f][1] = max(fam[f][1], r["scratch"])
+    assert "conv3x3_bwd_kernel" not in fam, fam["conv3x3_bwd_kernel"]
+    allowed = {"conv1x1_bwd_kernel": (15, 320), "conv1x1_stream_kernel": (5, 340), "conv1x1_tile_kernel": (2, 12),
+               "conv3x3_halo_kernel": (19, 104), "conv3x3_lds_fp8_kernel": (11, 96), "conv3x3_lds_kernel": (18, 76),
+               "conv3x3_ws_kernel": (2, 84), "conv_gather_kernel": (7, 196), "conv_wgrad_kernel": (9, 8)}
+    for f, (cnt, worst) in fam.items():
+        assert f in allowed, (f, cnt, worst)
+        assert cnt <= allowed[f][0] and worst <= allowed[f][1], (f, cnt, worst, allowed[f])

@@ -1,4 +1,5 @@
-"""bench.py with module flags of ``ops`` overridden (development aid): EXP=TWO_LANES=False,WGRAD_SIDE_STREAM=False python tools/exp_bench.py ..."""
+"""bench.py with default execution options (``ops.DEFAULTS``: they seed every network built afterwards) overridden -- development aid:
+EXP=wgrad_side_stream=False,fuse_3x3_backward=False python tools/exp_bench.py ..."""
 import os, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(root, "iea-gan_amd"), root]
@@ -9,8 +10,7 @@ import ops
 for kv in os.environ.get("EXP", "").split(","):
     if kv:
         k, v = kv.split("=")
-        assert hasattr(ops, k), k
-        setattr(ops, k, eval(v))
+        ops.DEFAULTS.update(**{k: eval(v)})
 import bench
 if os.environ.get("CFG"):                  # CFG=sn_prefetch=False,... : overrides of the benchmark's train configuration
     _base = bench.bench_config

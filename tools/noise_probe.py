@@ -21,7 +21,8 @@ for side, two, f1, f3 in settings:
     G, D = build_product(cfg, g_state, d_state, "cuda:0")
     z_, y_ = utils.prepare_z_y(n, G.dim_z, cfg["n_classes"], device="cuda:0")
     train = train_fns.GAN_training_function(G, D, model.G_D(G, D), z_, y_, None, {"itr": 1}, cfg, "cuda:0")
-    ops.WGRAD_SIDE_STREAM, ops.TWO_STAGE_WGRAD, ops.FUSE_1X1_BACKWARD, ops.FUSE_3X3_BACKWARD = side, two, f1, f3
+    for net in (G, D):
+        ops.set_options(net, wgrad_side_stream=side, two_stage_wgrad=two, fuse_1x1_backward=f1, fuse_3x3_backward=f3)
     out = train(x, y, noise=noise)
     torch.cuda.synchronize()
     names = [k for k, _ in G.named_parameters()]
