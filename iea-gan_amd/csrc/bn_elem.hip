@@ -247,7 +247,7 @@ extern "C" int ieagan_prologue_bwd(const void* da, const void* x, int Cx, const 
 // ------------------------------------------------------------------------------------------------
 #define BNF_CH 32
 #define BNF_MAXE 16
-#define BNF_SLOTS_PER_ROW 128      // slots one block row folds at most before the work is split (G = ceil(R / 128), <= 16)
+#define BNF_SLOTS_PER_ROW 256      // slots one block row folds at most before the work is split (G = ceil(R / 256), <= 16): 16 loads per thread, one batch
 
 __device__ __forceinline__ void sc1_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float sc1_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -318,8 +318,14 @@ __global__ __launch_bounds__(1024) void bn_finalize_fwd_kernel(const float* __re
             if (!last_row_arrives((int*)scratch, cb, G, &s_flag)) return;
             if (t < COLS && valid) {
                 for (int e = 0; e < E; ++e) {
+                    // all G partials requested before the first add (a load -> add -> load chain is one memory round trip per row)
+                    float buf[16];
+#pragma unroll
+                    for (int gg = 0; gg < 16; ++gg)
+                        buf[gg] = sc1_load(scratch + tick_floats + ((long)e * G + min(gg, G - 1)) * 2 * C + (long)which * C + c);
                     float sacc = 0.f;
-                    for (int gg = 0; gg < G; ++gg) sacc += sc1_load(scratch + tick_floats + ((long)e * G + gg) * 2 * C + (long)which * C + c);
+#pragma unroll
+                    for (int gg = 0; gg < 16; ++gg) sacc += (gg < G) ? buf[gg] : 0.f;
                     tot[e][t] = sacc;
                 }
             }
@@ -521,13 +527,22 @@ __global__ __launch_bounds__(1024) void bn_finalize_bwd_kernel(const float* __re
 #pragma unroll
             for (int e = 0; e < BNF_MAXE; ++e) {
                 if (e >= E) break;
+                float buf[8][4];                    // all G (<= 8) partial rows requested before the first add
+#pragma unroll
+                for (int gg = 0; gg < 8; ++gg) {
+                    const float* pay = scratch + tick_floats + (((long)e * G + min(gg, G - 1)) * 4) * C + c;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) buf[gg][q] = sc1_load(pay + q * C);
+                }
                 float a_ = 0.f, b_ = 0.f;
-                for (int gg = 0; gg < G; ++gg) {
-                    const float* pay = scratch + tick_floats + (((long)e * G + gg) * 4) * C + c;
-                    a_ += sc1_load(pay);
-                    b_ += sc1_load(pay + C);
-                    dg_sum += sc1_load(pay + 2 * C);
-                    db_sum += sc1_load(pay + 3 * C);
+#pragma unroll
+                for (int gg = 0; gg < 8; ++gg) {
+                    if (gg < G) {
+                        a_ += buf[gg][0];
+                        b_ += buf[gg][1];
+                        dg_sum += buf[gg][2];
+                        db_sum += buf[gg][3];
+                    }
                 }
                 drstd_e[e] = a_;
                 dmean_e[e] = b_;
