@@ -44,8 +44,8 @@ PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA peak of MI355X (MI355X_MICROARCH
 PEAK_HBM_GBS = 8000.0         # HBM3E spec (6.3 TB/s measured achievable)
 STEP_GFLOP = 5328.8           # algorithmic work per event-step (SURVEY 8d / BASELINE.md section 3)
 BENCH_LR = 1e-7               # see bench_config(): keeps both hinge terms of D unsaturated over the timed steps
-CPU_FULL_FILES = ("r03_cpu_full.json", "r02_cpu_full.json")                                      # newest first
-PMC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_final_pmc_traffic.json")      # newest first
+CPU_FULL_FILES = ("r04_cpu_full.json", "r03_cpu_full.json", "r02_cpu_full.json")                 # newest first
+PMC_FILES = ("r04_pmc_traffic.json", "r04a_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")      # newest first
 
 
 def synth_event(n, h, w, seed):
