@@ -15,6 +15,7 @@ def family(name):
     if n.startswith("conv_gather_kernel<1") or n.startswith("conv1x1_stream_kernel") or n.startswith("conv1x1_tile_kernel"): return "conv1x1_gather"      # (bench.py family names)
     if n.startswith("conv3x3_lds_kernel") or n.startswith("conv3x3_lds_fp8_kernel") or n.startswith("conv3x3_ws_kernel"): return "conv3x3_halo"
     if n.startswith("conv1x1_bwd_kernel"): return "conv1x1_bwd"
+    if n.startswith("conv3x3_bwd_kernel"): return "conv3x3_bwd"
     if n.startswith("d_stem_fwd_kernel"): return "d_stem_fwd"
     if n.startswith("d_stem_bwd_kernel"): return "d_stem_bwd"
     if n.startswith("wgrad_reduce_kernel"): return "conv3x3_wgrad"
