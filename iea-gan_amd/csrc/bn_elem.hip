@@ -284,6 +284,20 @@ __global__ __launch_bounds__(1024) void bn_finalize_fwd_kernel(const float* __re
     const bool valid = c < C;
     const int npe = N / E;
     const int rows = (ld == 0 && E == 1) ? 1 : N;
+    // the fan-out operands of the FIRST event (gain / bias rows: independent of the statistics) are requested before the slot fold, so
+    // that their memory round trip runs under it instead of behind it (two items per thread cover 64 images x 32 channels)
+    constexpr int FO = 2;
+    float pg[FO], pb[FO];
+    {
+        const int cnt0 = ((rows == 1) ? 1 : npe) * CH;
+#pragma unroll
+        for (int k = 0; k < FO; ++k) {
+            const int idx = min(t + k * 1024, cnt0 - 1);
+            const int n = ((rows == 1) ? 0 : 0) + idx / CH, cc = min(c0 + idx % CH, C - 1);
+            pg[k] = gain[(long)n * ld + cc];
+            pb[k] = bias[(long)n * ld + cc];
+        }
+    }
     if (training) {
         const int Rg = (R + G - 1) / G, r_lo = g * Rg, r_hi = min(R, r_lo + Rg);
         for (int e = 0; e < E; ++e) {
@@ -357,14 +371,23 @@ __global__ __launch_bounds__(1024) void bn_finalize_fwd_kernel(const float* __re
         __syncthreads();
         // fan-out over the images of this event: thread -> (image, channel), CH consecutive channels per image row
         const int n0 = (rows == 1) ? 0 : e * npe, n1 = (rows == 1) ? 1 : (e + 1) * npe;
-        for (int idx = t; idx < (n1 - n0) * CH; idx += 1024) {
+        auto fan = [&](int idx, float gv, float bv) {
             const int n = n0 + idx / CH, cc = idx % CH;
-            if (c0 + cc < C) {
-                const float gg = gain[(long)n * ld + c0 + cc] + (plus_one ? 1.f : 0.f);
-                const float sc = ms[1][cc] * gg;
-                scale[(long)n * C + c0 + cc] = sc;
-                shift[(long)n * C + c0 + cc] = bias[(long)n * ld + c0 + cc] - ms[0][cc] * sc;
+            const float sc = ms[1][cc] * (gv + (plus_one ? 1.f : 0.f));
+            scale[(long)n * C + c0 + cc] = sc;
+            shift[(long)n * C + c0 + cc] = bv - ms[0][cc] * sc;
+        };
+        const int cnt = (n1 - n0) * CH;
+        if (e == 0) {                                   // the operands requested up front (registers: static indices only)
+#pragma unroll
+            for (int k = 0; k < FO; ++k) {
+                const int idx = t + k * 1024;
+                if (idx < cnt && c0 + idx % CH < C) fan(idx, pg[k], pb[k]);
             }
+        }
+        for (int idx = t + (e == 0 ? FO * 1024 : 0); idx < cnt; idx += 1024) {
+            const int n = n0 + idx / CH, cc = idx % CH;
+            if (c0 + cc < C) fan(idx, gain[(long)n * ld + c0 + cc], bias[(long)n * ld + c0 + cc]);
         }
         __syncthreads();
     }
