@@ -18,6 +18,7 @@ CONV_FP8 = 4             # ieagan_conv_desc.flags bit: e4m3 MFMA operands in the
 CONV_NO_LDS_WEIGHTS = 2  # ieagan_conv_desc.flags bit: C = 64 / 128 3x3 layers through conv3x3_halo instead of conv3x3_lds
 CONV_FORCE_GATHER = 1   # ieagan_conv_desc.flags bit (tests): route a 3x3 layer through the gather kernel
 B1_OCC2, B1_OCC3, B1_TP32 = 1, 2, 4  # ieagan_conv1x1_bwd_desc.flags bits (benchmarks)
+BWD_NO_REDUCE = 16      # ieagan_conv1x1_bwd / ieagan_conv3x3_bwd: the caller folds the dW slabs (ieagan_wgrad_reduce)
 PROLOGUE_BWD_SLOTS = 64  # include/ieagan_hip.h: IEAGAN_PROLOGUE_BWD_SLOTS
 AUG_SLOTS = 128         # include/ieagan_hip.h: IEAGAN_AUG_SLOTS (per-image partial-sum slots of the DiffAugment entry points)
 BNB_REPL = 8            # replicas of the per-image accumulators of a BatchNorm-backward dgrad launch (common.h)
@@ -88,6 +89,7 @@ _SIGS = {
     "ieagan_conv3x3_bwd_supported": [i, i, i, i, i, i, i],
     "ieagan_conv3x3_bwd_slots": [C.POINTER(Conv3x3BwdDesc)],
     "ieagan_conv1x1_bwd_slots": [C.POINTER(Conv1x1BwdDesc)],
+    "ieagan_wgrad_reduce": [vp, vp, i, i, i, i, vp],
     "ieagan_conv_stats_slots": [C.POINTER(ConvDesc)],
     "ieagan_d_stem_fwd": [C.POINTER(DStemDesc), vp],
     "ieagan_d_stem_bwd": [C.POINTER(DStemDesc), vp],

@@ -475,7 +475,7 @@ static int b1_plan(const Bwd1Args& a, B1Plan& p) {
         if (a.lmode == 2) CHECK_ARG(a.H % 2 == 0 && a.W % 2 == 0, "conv1x1_bwd: half-resolution shortcut gradient needs even H, W");
     }
     CHECK_ARG(a.dx != nullptr || a.dw != nullptr, "conv1x1_bwd: nothing to compute");
-    CHECK_ARG((a.flags & ~(IEAGAN_B1_OCC2 | IEAGAN_B1_OCC3 | IEAGAN_B1_TP32)) == 0, "conv1x1_bwd: unknown flag bits 0x%x", a.flags);
+    CHECK_ARG((a.flags & ~(IEAGAN_B1_OCC2 | IEAGAN_B1_OCC3 | IEAGAN_B1_TP32 | IEAGAN_BWD_NO_REDUCE)) == 0, "conv1x1_bwd: unknown flag bits 0x%x", a.flags);
     CHECK_ARG(a.bn_slots >= 0, "conv1x1_bwd: bad bn_slots %d", a.bn_slots);
     CHECK_ARG(a.colsum == nullptr || a.dw != nullptr, "conv1x1_bwd: colsum rides on the weight gradient");
     const int tpi = a.H * a.W / TP;
@@ -559,6 +559,6 @@ extern "C" int ieagan_conv1x1_bwd(const ieagan_conv1x1_bwd_desc* d, void* stream
 #undef B1_CASE
 #undef B1_LAUNCH
     CHECK_LAUNCH("conv1x1_bwd");
-    if (a.partials != nullptr) return wgrad_reduce_launch(a.partials, a.dw, p.nblk, a.Cout, a.Kpad, a.Cin, st);
+    if (a.partials != nullptr && !(a.flags & IEAGAN_BWD_NO_REDUCE)) return wgrad_reduce_launch(a.partials, a.dw, p.nblk, a.Cout, a.Kpad, a.Cin, st);
     return 0;
 }

@@ -484,7 +484,7 @@ static int b3_plan(const Bwd3Args& a, B3Plan& p) {
     CHECK_ARG(a.n_per_event >= 0 && (a.n_per_event == 0 || a.N % a.n_per_event == 0), "conv3x3_bwd: N is not a whole number of events");
     CHECK_ARG((a.src.scale != nullptr) == (a.bn_acc != nullptr), "conv3x3_bwd: the affine prologue and bn_acc come together");
     CHECK_ARG(a.dx != nullptr && a.dw != nullptr && a.partials != nullptr, "conv3x3_bwd: dx, dw and the slab workspace are required");
-    CHECK_ARG(a.flags == 0 && a.bn_slots >= 0, "conv3x3_bwd: unknown flag bits 0x%x / bad bn_slots %d", a.flags, a.bn_slots);
+    CHECK_ARG((a.flags & ~IEAGAN_BWD_NO_REDUCE) == 0 && a.bn_slots >= 0, "conv3x3_bwd: unknown flag bits 0x%x / bad bn_slots %d", a.flags, a.bn_slots);
     p.tiles_w = a.W / B3_TW;
     p.tpi = p.tiles_w * (a.H / B3_TH);
     // ONE round of persistent blocks: whole blocks per image
@@ -578,5 +578,6 @@ extern "C" int ieagan_conv3x3_bwd(const ieagan_conv3x3_bwd_desc* d, void* stream
     else rc = (a.src.rs == 0) ? b3_dispatch<32, 0>(a, p, st) : b3_dispatch<32, 1>(a, p, st);
     if (rc != 0) return rc;
     CHECK_LAUNCH("conv3x3_bwd");
+    if (a.flags & IEAGAN_BWD_NO_REDUCE) return 0;
     return wgrad_reduce_launch(a.partials, a.dw, p.nblk, a.C, a.Kpad, 9 * a.C, st);
 }

@@ -363,6 +363,12 @@ int wgrad_reduce_launch(const float* part, float* dw, int S, int Cout, int Kpad,
     return 0;
 }
 
+extern "C" int ieagan_wgrad_reduce(const float* partials, float* dw, int S, int Cout, int Kpad, int K, void* stream) {
+    CHECK_ARG(partials != nullptr && dw != nullptr && S >= 1 && Cout >= 1 && Kpad % 4 == 0 && K <= Kpad, "wgrad_reduce: bad arguments");
+    ProfScope prof("wgrad_reduce", 0.0, 4.0 * ((double)S + 2.0) * Cout * Kpad, (hipStream_t)stream);
+    return wgrad_reduce_launch(partials, dw, S, Cout, Kpad, K, (hipStream_t)stream);
+}
+
 struct WgradPlan {
     int mt, gx, gy, gz, tpb, pad_rows;
     bool special;

@@ -113,10 +113,13 @@ class ExecOptions:
     fuse_shortcut_grad  residual-shortcut gradients added inside the dx-producing kernel (False: autograd adds)
     fuse_1x1_backward / fuse_3x3_backward (+ *_min_pixels)   the whole-backward kernels conv1x1_bwd / conv3x3_bwd (False: separate launches)
     fuse_d_stem         D.input_conv + the first DBlock's conv1 / conv_sc / pooled shortcut in one launch each way
-    b1_flags            ieagan_conv1x1_bwd_desc.flags (benchmarks: H.B1_OCC2 / H.B1_OCC3)"""
+    b1_flags            ieagan_conv1x1_bwd_desc.flags (benchmarks: H.B1_OCC2 / H.B1_OCC3)
+    fused_reduce_side_stream   the slab folds of the whole-backward kernels on the weight-gradient side stream (with wgrad_side_stream).
+                        OFF: measured 36.75-37.0 vs 34.75-34.97 ms per step on one box -- the side stream then sits behind every fused kernel
+                        of the large maps and the weight gradients queued after it start late"""
     FIELDS = dict(wgrad_side_stream=True, two_stage_wgrad=True, use_tr_read=True, fuse_bn_backward=True, fuse_shortcut_grad=True,
                   fuse_1x1_backward=True, fuse_1x1_min_pixels=1 << 16, fuse_3x3_backward=True, fuse_3x3_min_pixels=1 << 16,
-                  fuse_d_stem=True, b1_flags=0)
+                  fuse_d_stem=True, b1_flags=0, fused_reduce_side_stream=False)
     __slots__ = tuple(FIELDS)
 
     def __init__(self, like=None, **kw):
@@ -703,6 +706,29 @@ def _placeholder(like):
 # wgrad + bias column sums, every operand tile read once (ExecOptions.fuse_1x1_backward; tests compare it with the separate launches).
 
 
+def _fused_bwd_launch(name, d, rec, ws, dwp, Cout, K, operands):
+    """Launch a whole-backward kernel whose partial dW slabs sit in ``ws``.  ``ExecOptions.fused_reduce_side_stream`` (off by default: it
+    measured 2 ms slower) sends the slab fold (``wgrad_reduce``, ~10 us + a launch boundary per layer) to the weight-gradient side stream:
+    nothing reads dW before the end of the pass (``SNPass.flush`` joins the side stream)."""
+    o = opts_of(rec)
+    side_ok = ws is not None and o.wgrad_side_stream and o.fused_reduce_side_stream and getattr(rec, "deferred", False)
+    if side_ok:
+        d.flags |= H.BWD_NO_REDUCE
+    H.call(name, d, H.stream())
+    if side_ok:
+        dev = ws.device
+        fork = torch.cuda.Event()
+        fork.record(torch.cuda.current_stream())
+        side = wgrad_stream(dev)
+        with torch.cuda.stream(side):
+            side.wait_event(fork)
+            H.call("ieagan_wgrad_reduce", ws.data_ptr(), dwp.data_ptr(), ws.numel() // (Cout * rec.kpad), Cout, rec.kpad, K, H.stream())
+        for t in (ws,) + tuple(operands):           # read by the side stream after this node has handed them back to the pool
+            if t is not None:
+                t.record_stream(side)
+        rec.pass_.side = side
+
+
 def _fused_1x1_eligible(ctx, dout, dstats):
     """Can ``ConvFn.backward`` take the fused 1x1 backward for this node?  (shape instantiated, big map, both gradients wanted, a
     shortcut-gradient link the kernel can add in place.)"""
@@ -777,10 +803,11 @@ def _conv1x1_backward_fused(ctx, dout, dstats):
         acc = zeros((N, d.bn_slots, 2, Cin), dev)
         d.bn_acc = acc.data_ptr()
     ws_n = H.lib().ieagan_conv1x1_bwd_workspace(d)
+    ws = None
     if ws_n > 0:
         ws = torch.empty(ws_n, dtype=torch.float32, device=dev)
         d.partials = ws.data_ptr()
-    H.call("ieagan_conv1x1_bwd", d, H.stream())
+    _fused_bwd_launch("ieagan_conv1x1_bwd", d, rec, ws, dwp, Cout, Cin, ())
     # ---- residual operands (as the generic path, on g_eff)
     gl = geff if eff else g
     d_ra = d_rb = None
@@ -872,7 +899,7 @@ def _conv3x3_backward_fused(ctx, dout, dstats):
             raise RuntimeError(f"ieagan_conv3x3_bwd_slots failed: {H.lib().ieagan_last_error().decode()}")
         acc = zeros((N, d.bn_slots, 2, C), dev)
         d.bn_acc = acc.data_ptr()
-    H.call("ieagan_conv3x3_bwd", d, H.stream())
+    _fused_bwd_launch("ieagan_conv3x3_bwd", d, rec, ws, dwp, C, 9 * C, ())
     dscale = dshift = None
     if has_aff:
         bn_link = getattr(scale, "_bn_link", None)

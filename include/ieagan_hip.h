@@ -153,10 +153,15 @@ typedef struct {
 #define IEAGAN_B1_OCC2 1
 #define IEAGAN_B1_OCC3 2
 #define IEAGAN_B1_TP32 4          /* 32-pixel wave tiles everywhere */
+#define IEAGAN_BWD_NO_REDUCE 16   /* ieagan_conv1x1_bwd / ieagan_conv3x3_bwd: leave the partial dW slabs in `partials` -- the caller folds them with
+                                   * ieagan_wgrad_reduce (e.g. on a side stream: nothing in a backward pass reads dW before its end) */
 int ieagan_conv1x1_bwd(const ieagan_conv1x1_bwd_desc* d, void* stream);
 long ieagan_conv1x1_bwd_workspace(const ieagan_conv1x1_bwd_desc* d);
 int ieagan_conv1x1_bwd_supported(int Cin, int Cout, int rs, int affine);
 int ieagan_conv1x1_bwd_slots(const ieagan_conv1x1_bwd_desc* d);      /* blocks per image of the launch */
+/* second stage of every two-stage weight-gradient accumulation: dw[Cout][Kpad] += sum over the S slabs of `partials` ([S][Cout][Kpad]; columns
+ * k >= K are padding).  S = workspace floats / (Cout * Kpad). */
+int ieagan_wgrad_reduce(const float* partials, float* dw, int S, int Cout, int Kpad, int K, void* stream);
 
 /* ---- the whole backward of a 3x3 convolution with Cin = Cout = C in {16, 32} on a large feature map in one launch (conv3x3_bwd.hip) ----
  * Replaces, per layer and backward pass, ieagan_effgrad -> ieagan_conv_forward (as dgrad) [-> ieagan_prologue_bwd] -> ieagan_conv_wgrad, i.e.
@@ -183,7 +188,7 @@ typedef struct {
     float* dw;                /* fp32 [C][Kpad], accumulated                                                         */
     float* partials;          /* workspace of ieagan_conv3x3_bwd_workspace(d) floats: one dW slab per block          */
     float* colsum;            /* optional fp32 [32][C] caller-zeroed replicas (bias gradient)                        */
-    int flags;                /* 0                                                                                   */
+    int flags;                /* 0 | IEAGAN_BWD_NO_REDUCE                                                            */
     int bn_slots;             /* bn_acc is [N][bn_slots][2][C]; == ieagan_conv3x3_bwd_slots(d): one adder per slot (bit-reproducible); 0: 8 */
 } ieagan_conv3x3_bwd_desc;
 int ieagan_conv3x3_bwd(const ieagan_conv3x3_bwd_desc* d, void* stream);
