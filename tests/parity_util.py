@@ -99,13 +99,14 @@ def _flat_grads(net, grads):
 
 
 def step_parity(resolution=64, H_base=1, device="cuda:0", verbose=False, n=40, events=1, state_check=False, oracle_bf16=False,
-                inputs=None, y_g=None, sn_warm=0, **cfg_over):
+                inputs=None, y_g=None, sn_warm=0, hip_only=False, **cfg_over):
     """One full train(x, y) on the HIP path vs the oracle on identical weights / noise: the 5 losses and the flat G / D
     gradients (cosine, rel-L2); with ``state_check`` also the post-step state (parameters after Adam, spectral-norm
     ``u0`` / ``sv0``, BatchNorm running statistics).  ``n`` < 40 runs a sub-event of the first n sensors (full
     256x768 resolution stays affordable for the CPU oracle), ``events`` > 1 the E-events-per-step path (configs[3]).
     ``oracle_bf16``: additionally run the oracle with bf16-rounded conv operands / outputs (``O.ROUND_BF16``) and report
-    how far THAT moves the same quantities -- the rounding-noise floor the tolerances are stated against."""
+    how far THAT moves the same quantities -- the rounding-noise floor the tolerances are stated against.
+    ``hip_only``: no oracle run -- the HIP path's losses and flat gradients alone, for comparisons of two HIP runs with each other."""
     import model
     import train_fns
     import utils
@@ -148,6 +149,8 @@ def step_parity(resolution=64, H_base=1, device="cuda:0", verbose=False, n=40, e
     torch.cuda.synchronize()
     g_grad = G._arena.grad.clone().cpu()
     d_grad = D._arena.grad.clone().cpu()
+    if hip_only:
+        return {"losses": out, "G_grad": g_grad, "D_grad": d_grad}
 
     def run_oracle():
         gsd, gp = O.as_trainable(g_state)

@@ -103,6 +103,16 @@ def test_train_step_256x768_full_event_vs_oracle():
     assert st["D_update_sign_agree"] >= 0.9 and st["G_update_sign_agree"] >= 0.85, st
 
 
+def _same_twice_is_once(same, one):
+    """E = 2 of one event twice vs that event once, two HIP runs: the losses agree, and so do the (event-averaged) flat gradients --
+    they are sums of the same per-event terms in a different grouping, so only fp32 accumulation order separates them."""
+    from parity_util import rel_l2
+    for k in one["losses"]:
+        assert abs(same["losses"][k] - one["losses"][k]) <= 2e-3 * max(1.0, abs(one["losses"][k])), (k, same["losses"], one["losses"])
+    for k in ("G_grad", "D_grad"):
+        assert rel_l2(same[k], one[k]) <= 2e-2, (k, rel_l2(same[k], one[k]))
+
+
 def test_train_step_events_con_reg_vs_oracle_and_fixture(golden_dir):
     """BASELINE configs[3] at 40x64x64: E = 2 events per step batched on the leading dimension (per-event BatchNorm
     statistics / RRM / loss Grams, averaged gradients, mean running-stat update), DiffAugment + CR_DiffAug consistency
@@ -121,10 +131,9 @@ def test_train_step_events_con_reg_vs_oracle_and_fixture(golden_dir):
     assert st["G_u0_rel_max"] <= 2e-2 and st["D_u0_rel_max"] <= 2e-2 and st["G_bn_running_rel_max"] <= 5e-2, st
     assert st["G_param_rel"] <= 1e-3 and st["D_param_rel"] <= 1e-3, st
     # E = 2 of one event twice == that event once (same draws): the event dimension must not mix events
-    same = step_parity(64, 1, events=2, inputs=([xs[0], xs[0]], [noises[0], noises[0]]), Con_reg=True)
-    one = step_parity(64, 1, events=1, inputs=([xs[0]], [noises[0]]), Con_reg=True)
-    for k in one["losses"]:
-        assert abs(same["losses"][k] - one["losses"][k]) <= 2e-3 * max(1.0, abs(one["losses"][k])), (k, same["losses"], one["losses"])
+    same = step_parity(64, 1, events=2, inputs=([xs[0], xs[0]], [noises[0], noises[0]]), Con_reg=True, hip_only=True)
+    one = step_parity(64, 1, events=1, inputs=([xs[0]], [noises[0]]), Con_reg=True, hip_only=True)
+    _same_twice_is_once(same, one)
 
 
 def test_train_step_events_con_reg_256x768_vs_oracle():
@@ -146,10 +155,9 @@ def test_train_step_events_con_reg_256x768_vs_oracle():
     x0 = O.synth_event(8, 256, 768, 303)
     nz = make_noise(8, 256, 768, 909)
     nz["cr"] = O.cr_draws(8, 256, 768, generator=torch.Generator().manual_seed(77))
-    same = step_parity(256, 3, n=8, events=2, inputs=([x0, x0], [nz, nz]), Con_reg=True)
-    one = step_parity(256, 3, n=8, events=1, inputs=([x0], [nz]), Con_reg=True)
-    for k in one["losses"]:
-        assert abs(same["losses"][k] - one["losses"][k]) <= 2e-3 * max(1.0, abs(one["losses"][k])), (k, same["losses"], one["losses"])
+    same = step_parity(256, 3, n=8, events=2, inputs=([x0, x0], [nz, nz]), Con_reg=True, hip_only=True)
+    one = step_parity(256, 3, n=8, events=1, inputs=([x0], [nz]), Con_reg=True, hip_only=True)
+    _same_twice_is_once(same, one)
 
 
 @pytest.mark.parametrize("tag,over", [("joint", {"split_D": False}), ("proj", {"conditional_strategy": "Proj"})])
