@@ -48,7 +48,7 @@ __host__ __device__ constexpr int wg_stride(int C) { return ((C / 16) % 2 == 0) 
 //         the MFMAs of the current one (RS != 2).  These launches run few, long blocks (the larger dW is, the fewer pixel splits pay
 //         off against the atomic tail), so global-memory latency must be hidden inside the block, not by occupancy.
 template <int TAPS, bool AFF, bool RELU, int RS, int MT, bool TR, int NJ, int CINV>
-__global__ __launch_bounds__(256, (CINV > 0 ? (CINV == 16 ? 4 : (CINV == 32 ? 3 : 1)) : (TR ? (MT == 4 ? 3 : (MT == 8 ? 2 : 1)) : 1))) void conv_wgrad_kernel(WgradArgs a) {
+__global__ __launch_bounds__(256, (CINV > 0 ? (CINV == 16 ? 4 : (CINV == 32 ? 3 : 1)) : (TR ? (MT >= 4 ? 2 : 1) : 1))) void conv_wgrad_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int HALO = (TAPS == 9) ? 1 : 0;
     constexpr int AW = WG_TW + 2 * HALO, AH = WG_TH + 2 * HALO;
@@ -169,20 +169,86 @@ __global__ __launch_bounds__(256, (CINV > 0 ? (CINV == 16 ? 4 : (CINV == 32 ? 3 
                 *(bf16x8*)(lds_a + (idx / (CINV > 0 ? CINV / 8 : 1)) * AS + (idx % (CINV > 0 ? CINV / 8 : 1)) * 8) = o;
             }
         } else {
-            // ---- stage g tile: 128 pixels x GC couts, 16-byte chunks
-            for (int idx = threadIdx.x; idx < WG_TH * WG_TW * (GC / 8); idx += 256) {
+            // ---- stage the g tile (128 pixels x GC couts) and the a tile (+halo, prologue fused) in batches of independent 16-byte
+            // loads per thread: coordinates clamped into the image (every address valid, no branch around a load), the padding /
+            // ragged edge zeroed through a mask afterwards.  (As rolled load -> wait -> ds_write loops these kept ONE 16-byte load per
+            // thread in flight: 20 serial memory round trips per 82 KB tile at Cin = 256, 16-18 us per tile.)
+            constexpr int GTOT = WG_TH * WG_TW * (GC / 8);
+            // opaque per tile: the chunk -> (pixel, channel) index math below is tile-invariant, and hoisted out of the tile loop it
+            // takes ~50 registers next to the accumulators (spills whose reloads share the counter of the very loads batched here)
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            bf16x8 vg[GCH];
+            unsigned okb = 0;
+#pragma unroll
+            for (int j = 0; j < GCH; ++j) {
+                const int idx = tid + j * 256;
                 const int px = idx / (GC / 8), cc = idx - px * (GC / 8);
                 const int hh = h0 + px / WG_TW, ww = w0 + px % WG_TW;
-                bf16x8 v = zero8();
-                if (hh < H && ww < W && cout0 + cc * 8 < a.Cout) v = *(const bf16x8*)((const bf16*)a.g + (((long)n * H + hh) * W + ww) * a.Cg + cout0 + cc * 8);
-                *(bf16x8*)(lds_g + px * GS + cc * 8) = v;
+                const bool ok = idx < GTOT && hh < H && ww < W && cout0 + cc * 8 < a.Cout;
+                vg[j] = *(const bf16x8*)((const bf16*)a.g + (((long)n * H + min(hh, H - 1)) * W + min(ww, W - 1)) * a.Cg + cout0 + (ok ? cc * 8 : 0));
+                okb |= (unsigned)ok << j;
             }
-            // ---- stage a tile (+halo) with the fused prologue
-            for (int idx = threadIdx.x; idx < AH * AW * (Cin / 8); idx += 256) {
-                const int hp = idx / (Cin / 8), cc = idx - hp * (Cin / 8);
-                const int hh = h0 - HALO + hp / AW, ww = w0 - HALO + hp % AW;
-                const bf16x8 v = gather8<AFF, RELU, RS>(a.src, H, W, n, hh, ww, cc * 8, true);
-                *(bf16x8*)(lds_a + hp * AS + cc * 8) = v;
+            constexpr int SB = (RS == 2) ? (MT == 8 ? 1 : 4) : (MT == 8 ? 4 : 8);      // chunks per thread and batch (RS == 2: four source pixels per chunk;
+                                                                              // MT == 8: 128 accumulator registers stay live across the staging)
+            constexpr int NQ = (RS == 2) ? 4 : 1;
+            const int cpp = Cin >> 3, atot = AH * AW * cpp;
+            for (int b0 = 0; b0 < atot; b0 += SB * 256) {
+                bf16x8 raw[SB][NQ];
+                unsigned oka2 = 0;
+#pragma unroll
+                for (int j = 0; j < SB; ++j) {
+                    const int idx = b0 + j * 256 + tid;
+                    const int idc = min(idx, atot - 1);
+                    const int hp = idc / cpp, cc = idc - hp * cpp;
+                    const int hh = h0 - HALO + hp / AW, ww = w0 - HALO + hp % AW;
+                    if (idx < atot && hh >= 0 && hh < H && ww >= 0 && ww < W) oka2 |= 1u << j;
+                    const int hc = min(max(hh, 0), H - 1), wc = min(max(ww, 0), W - 1);
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const int sh_ = (RS == 2) ? 2 * hc + (q >> 1) : ((RS == 1) ? (hc >> 1) : hc);
+                        const int sw_ = (RS == 2) ? 2 * wc + (q & 1) : ((RS == 1) ? (wc >> 1) : wc);
+                        raw[j][q] = *(const bf16x8*)((const bf16*)a.src.x + (((long)n * a.src.Hs + sh_) * a.src.Ws + sw_) * a.src.Cx + cc * 8);
+                    }
+                }
+                if (b0 == 0) {                            // the g chunks went out first: store them behind the a requests
+#pragma unroll
+                    for (int j = 0; j < GCH; ++j) {
+                        const int idx = tid + j * 256;
+                        if (idx < GTOT) *(bf16x8*)(lds_g + (idx / (GC / 8)) * GS + (idx % (GC / 8)) * 8) = (okb & (1u << j)) ? vg[j] : zero8();
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < SB; ++j) {
+                    const int idx = b0 + j * 256 + tid;
+                    if (idx >= atot) continue;
+                    const int idc = min(idx, atot - 1);       // (== idx here: the same expression as above, one division for both)
+                    const int hp = idc / cpp, cc = idc - hp * cpp;
+                    bf16x8 o = zero8();
+                    if (oka2 & (1u << j)) {
+                        if (RS != 2 && !AFF && !RELU) {
+                            o = raw[j][0];
+                        } else if (RS != 2 && !AFF && RELU) {
+                            o = relu8(raw[j][0]);
+                        } else {
+                            float acc8[8];
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) acc8[i] = 0.f;
+#pragma unroll
+                            for (int q = 0; q < NQ; ++q) {
+                                float v[8];
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) v[i] = bf2f(raw[j][q][i]);
+                                xform8<AFF, RELU>(v, a.src, n, cc * 8);
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) acc8[i] += v[i];
+                            }
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) o[i] = f2bf((RS == 2 ? 0.25f : 1.f) * acc8[i]);
+                        }
+                    }
+                    *(bf16x8*)(lds_a + hp * AS + cc * 8) = o;
+                }
             }
         }
         __syncthreads();
@@ -416,6 +482,21 @@ static int wgrad_plan(const WgradArgs& a, int use_tr, WgradPlan& p) {
     if (p.special && a.Cin <= 64) blocks_goal = a.Cin == 16 ? 1024 : (a.Cin == 32 ? 512 : 256);
     long target = blocks_goal / (p.gy * p.gz);
     if (target < 64) target = 64;
+    {
+        // Traffic rule: every pixel split costs one slab of dW written and read back.  The step as a whole is HBM-bound and these
+        // launches run beside the main stream, so what they cost the step is the bytes they move, not their stand-alone latency
+        // (measured: skipping them all saves 3.3 ms = their share of the step's traffic): no more splits than make the slabs as heavy
+        // as the operands, but no block longer than `maxt` tiles.
+        constexpr double tf = 2.0;          // slabs (written + read back) up to twice the operand bytes: in-step scan {0.5, 1, 2, 3, 4, 8} x
+        constexpr long maxt = 16;           // {8, 16, 32, 64} serial tiles, 40-step A/B on one box: 33.64-33.78 ms against 33.96-33.98 without the rule
+        const double in_bytes = 2.0 * a.N * ((double)a.src.Hs * a.src.Ws * a.Cin + (double)a.H * a.W * a.Cout);
+        const double dw_bytes = 4.0 * a.Cout * a.Kpad;
+        long cap = (long)(tf * in_bytes / (2.0 * dw_bytes));
+        const long pmin = (tiles + maxt - 1) / maxt;
+        if (cap < pmin) cap = pmin;
+        if (cap < 2) cap = 2;
+        if (target > cap) target = cap;
+    }
     int tpb = (int)((tiles + target - 1) / target);
     if (tpb < 1) tpb = 1;
     p.tpb = tpb;
