@@ -5,11 +5,11 @@
 //     with an XOR swizzle of their 16-byte chunks (a padded image does not fit 160 KB next to the weights); every MFMA operand
 //     is one conflict-free ds_read_b128.  (Measured on the previous design: the per-wave 16-byte weight fetches through L1 ran
 //     at ~16 B/clk/CU and left the MFMAs waiting -- K loop alone 60 of 106 us at 64x192.)
-//   * all global traffic of a tile is requested up front (weights + halo: ~20 independent 16-byte loads per thread), then the
-//     K loop runs from LDS only, software-pipelined one k-step ahead;
-//   * C = 64: 8 waves share one 16x32-pixel tile x 64 couts (two waves per SIMD: one wave's LDS reads overlap the other's
-//     MFMAs); C = 128: 4 waves, 8x16 pixels x 32 couts -- small tiles because these layers live on 8x24 / 16x48 maps and
-//     need >= 256 blocks to fill the chip.
+//   * the weights are loaded once per (persistent) block, the halo of the NEXT tile is requested into registers before the K loop
+//     of the current one; the K loop runs from LDS only, software-pipelined one k-step ahead;
+//   * C = 64: 8 waves share one 8x32-pixel tile x 64 couts (two waves per SIMD: one wave's LDS reads overlap the other's
+//     MFMAs), ONE round of persistent blocks; C = 128: 4 waves, 8x16 pixels x 32 couts -- small tiles because these layers live
+//     on 8x24 / 16x48 maps and need >= 256 blocks to fill the chip.
 // Prologue (per-(n,c) affine + ReLU, nearest x2 upsample of the source) and epilogue (bias, ReLU mask, residual, statistics,
 // BatchNorm-backward mode) are those of conv3x3_halo (shared code in conv_common.h).
 #include "common.h"
@@ -35,13 +35,17 @@ __device__ __forceinline__ int swz(int key, int chunk) {
 }
 
 // LDS image of one block (weight slice + halo): above 80 KB only ONE block fits a CU, whatever the register budget says
-template <int CIN, int NT, int TH, int TW>
-constexpr int lds_image_bytes() { return NT * 16 * 9 * CIN * 2 + (TH + 2) * (TW + 2) * CIN * 2; }
+// (the halo region also carries the per-wave epilogue transpose buffers: sized for the larger of the two)
+template <int CIN, int NT, int TH, int TW, int NW = 0>
+constexpr int lds_image_bytes() {
+    const int halo = (TH + 2) * (TW + 2) * CIN * 2, epi = NW * EpiLds<NT>::FLOATS * 4;
+    return NT * 16 * 9 * CIN * 2 + (halo > epi ? halo : epi);
+}
 
 // FULL: H % TH == 0 and W % TW == 0 -- every pixel of every tile exists, the epilogue's stores are unconditional and the compiler can
 // count them when the prefetched halo of the next tile is consumed (instead of draining the counter, stores included).
 template <bool AFF, bool RELU, int RS, int CIN, int NT, int TH, int TW, int NW, bool BNB, bool FULL = false>
-__global__ __launch_bounds__(NW * 64, (lds_image_bytes<CIN, NT, TH, TW>() > 80 * 1024 ? 1 : NW / 4)) void conv3x3_lds_kernel(ConvArgs a, int tiles_w, int tiles_h, int tpe, int tpb, int nblk, int bpe) {
+__global__ __launch_bounds__(NW * 64, (lds_image_bytes<CIN, NT, TH, TW, NW>() > 80 * 1024 ? 1 : NW / 4)) void conv3x3_lds_kernel(ConvArgs a, int tiles_w, int tiles_h, int tpe, int tpb, int nblk, int bpe) {
     constexpr int AW = TW + 2, AH = TH + 2;
     constexpr int K = 9 * CIN;
     constexpr int KS = K / 32;
@@ -54,7 +58,7 @@ __global__ __launch_bounds__(NW * 64, (lds_image_bytes<CIN, NT, TH, TW>() > 80 *
     constexpr int W_BYTES = NT * 16 * K * 2;
     constexpr int HALO_BYTES = AH * AW * CIN * 2;
     constexpr int EPI_BYTES = NW * EpiLds<NT>::FLOATS * 4;
-    static_assert(EPI_BYTES <= HALO_BYTES && NW * STATS_SX_FLOATS * 4 <= HALO_BYTES, "epilogue / fold scratch reuse the halo region");
+    static_assert(NW * STATS_SX_FLOATS * 4 <= (HALO_BYTES > EPI_BYTES ? HALO_BYTES : EPI_BYTES), "epilogue / fold scratch reuse the halo region");
     extern __shared__ __attribute__((aligned(16))) char smem_all[];
     char* wsm = smem_all;                       // weights
     char* hsm = smem_all + W_BYTES;             // halo, later the epilogue transpose buffers
@@ -90,12 +94,14 @@ __global__ __launch_bounds__(NW * 64, (lds_image_bytes<CIN, NT, TH, TW>() > 80 *
     for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
     int aff_n = -1;
     // The raw halo of tile t+1 is requested into registers right before the K loop of tile t and written to LDS (prologue applied)
-    // after tile t's epilogue: with one block per CU (152 / 120 KB of LDS) nothing else hides a tile's load latency.  The requests
+    // after tile t's epilogue: with one block per CU (117 / 120 KB of LDS) nothing else hides a tile's load latency.  The requests
     // are unconditional (coordinates clamped into the image, the padding ring zeroed through a mask; past the block's last tile
     // the last tile is requested again and dropped) so that the compiler can count what is in flight behind them.
-    // (C = 128 only: the 8-wave C = 64 block sits at its 256-register cap and the extra live range spills -- 65 -> 70 us; C = 128
-    //  16x48 29.7 -> 27.2 us, 8x24 20.3 -> 16.8 us on one box)
-    constexpr bool XPF = CIN >= 128;
+    // (C = 128: 16x48 29.7 -> 27.2 us, 8x24 20.3 -> 16.8 us.  C = 64 took this form in round 4 with the 8x32 tile: the 16x32 tile it
+    //  replaced sat at the 256-register cap of an 8-wave block and spilled once the prefetch registers were added; 8x32 halves the
+    //  accumulators -- 64x192 forward 63.6 -> 56.1 us, with BatchNorm prologue 70.8 -> 58.0, masked dgrad 73.1 -> 66.0 on one box.)
+    // (the 4-wave C = 64 form of the small maps runs two blocks per CU, which overlap each other: with the prefetch 20.6 -> 22.8 us at 32x96)
+    constexpr bool XPF = CIN >= 128 || NW == 8;
     constexpr int HTOT = AH * AW * CH, HIT = XPF ? (HTOT + NTHR - 1) / NTHR : 1;
     bf16x8 rawn[HIT];
     unsigned okn = 0;
@@ -286,14 +292,14 @@ static int lds_launch(const ConvArgs& a, hipStream_t st) {
         const int gy = (a.Cout + 16 * NTV - 1) / (16 * NTV);                                                                       \
         /* ONE round of persistent blocks (one or two per CU, by the LDS image): a block loads its weight slice once and keeps the \
            next tile's halo in flight while it computes */                                                                         \
-        const int slots = (CINV) >= 128 ? 256 * (lds_image_bytes<CINV, NTV, THV, TWV>() > 80 * 1024 ? 1 : 2) : 512;                \
+        const int slots = 256 * (lds_image_bytes<CINV, NTV, THV, TWV, NWV>() > 80 * 1024 ? 1 : 2);                \
         int tpb = (ntiles * gy + slots - 1) / slots;                                                                               \
         if (tpb < 1) tpb = 1;                                                                                                      \
         if (tpb > tpe) tpb = tpe;                                                                                                  \
         const int bpe = (tpe + tpb - 1) / tpb;                                                                                     \
         const int nblk = bpe * n_events;                                                                                           \
         CONV_PLAN_POINT(bpe, 1)                                                                                                    \
-        const size_t lds = (size_t)NTV * 16 * 9 * CINV * 2 + (size_t)(THV + 2) * (TWV + 2) * CINV * 2;                             \
+        const size_t lds = (size_t)lds_image_bytes<CINV, NTV, THV, TWV, NWV>();                             \
         const bool full = a.H % THV == 0 && a.W % TWV == 0;                                                                        \
         auto kern = full ? conv3x3_lds_kernel<AFF, RELU, RS, CINV, NTV, THV, TWV, NWV, BNB, true>                                  \
                          : conv3x3_lds_kernel<AFF, RELU, RS, CINV, NTV, THV, TWV, NWV, BNB, false>;                                \
@@ -312,7 +318,7 @@ static int lds_launch(const ConvArgs& a, hipStream_t st) {
     // 4-wave 8x16 form with 32 output channels per block (60 KB of LDS: two blocks per CU) gives 8x as many blocks
     if (a.Cin == 64 && a.Cout % 64 == 0 && a.H >= 8 && a.W >= 16 &&
         (long)a.N * ((a.H + 15) / 16) * ((a.W + 31) / 32) * (a.Cout / 64) < 400) LDS_LAUNCH(64, 2, 8, 16, 4)
-    if (a.Cin == 64 && a.Cout % 64 == 0 && a.H >= 16 && a.W >= 32) LDS_LAUNCH(64, 4, 16, 32, 8)
+    if (a.Cin == 64 && a.Cout % 64 == 0 && a.H >= 16 && a.W >= 32) LDS_LAUNCH(64, 4, 8, 32, 8)
     if (a.Cin == 128 && a.Cout % 32 == 0 && a.H >= 8 && a.W >= 16) LDS_LAUNCH(128, 2, 8, 16, 4)
 #undef LDS_LAUNCH
     return 0;

@@ -372,10 +372,10 @@ def test_register_spill_ratchet_of_the_built_library():
         if r["scratch"]:
             fam[f][0] += 1
             fam[f][1] = max(fam[f][1], r["scratch"])
-    for clean in ("conv3x3_bwd_kernel", "conv_wgrad_kernel"):         # spill-free families stay spill-free
+    for clean in ("conv3x3_bwd_kernel", "conv_wgrad_kernel", "conv3x3_lds_kernel"):         # spill-free families stay spill-free
         assert clean not in fam, (clean, fam[clean])
     allowed = {"conv1x1_bwd_kernel": (15, 320), "conv1x1_stream_kernel": (5, 340), "conv1x1_tile_kernel": (2, 12),
-               "conv3x3_halo_kernel": (19, 104), "conv3x3_lds_fp8_kernel": (11, 96), "conv3x3_lds_kernel": (18, 76),
+               "conv3x3_halo_kernel": (19, 104), "conv3x3_lds_fp8_kernel": (11, 96),
                "conv3x3_ws_kernel": (2, 84), "conv_gather_kernel": (7, 196)}
     for f, (cnt, worst) in fam.items():
         assert f in allowed, (f, cnt, worst)

@@ -4,6 +4,8 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(root, "iea-gan_amd"), root]
 import torch
 import _hip as H
+if os.environ.get("CB_LIB"):
+    H.LIB_PATH = os.environ["CB_LIB"]
 import ops
 
 N, Hh, Ww, Cin, Cout, taps = map(int, sys.argv[1:7])
