@@ -13,9 +13,10 @@
 namespace {
 
 constexpr int TM = 64;        // tile edge
-constexpr int TK = 16;        // reduce chunk
+constexpr int TK = 32;        // reduce chunk (two 16-deep MFMA groups)
 constexpr int LDK = TK + 4;   // padded LDS row: 16 consecutive rows of a fragment read land on distinct banks
-constexpr int KSPLIT = 2048;  // reduce length per Gram work item
+constexpr int KSPLIT = 512;   // reduce length per Gram work item
+constexpr int NI = (TM * TK) / 256;      // staged elements per thread, operand and chunk
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -25,23 +26,36 @@ struct Operand {              // element (m, k) of a [M x Kd] operand lives at p
     int M, Kd;
 };
 
-// Stage a [TM x TK] chunk (rows m0.., reduce k0..) into LDS as s[m][k]; out-of-range -> 0.
-__device__ __forceinline__ void stage(const Operand& o, int m0, int k0, int kend, float (*s)[LDK], int tid) {
+// One [TM x TK] chunk of an operand (rows m0.., reduce k0..): `fetch` requests this thread's NI elements into registers (out-of-range
+// -> 0), `put` writes them to LDS as s[m][k].  Split so that the NEXT chunk is in flight while the MFMAs of the current one run: as
+// one load -> LDS -> barrier -> MFMA sequence per 16-deep chunk every chunk paid a full memory round trip (128 of them per work item:
+// the two launches took 0.41 ms at the end of the generator phase).
+__device__ __forceinline__ void elem(const Operand& o, int e, int& m, int& k) {
+    if (o.cs == 1) { m = e / TK; k = e % TK; } else { k = e / TM; m = e % TM; }      // consecutive threads along the contiguous axis
+}
+__device__ __forceinline__ void fetch(const Operand& o, int m0, int k0, int kend, float (&r)[NI], int tid) {
 #pragma unroll
-    for (int i = 0; i < (TM * TK) / 256; ++i) {
-        int e = tid + 256 * i;
+    for (int i = 0; i < NI; ++i) {
         int m, k;
-        if (o.cs == 1) { m = e / TK; k = e % TK; } else { k = e / TM; m = e % TM; }      // consecutive threads along the contiguous axis
-        int gm = m0 + m, gk = k0 + k;
-        float v = 0.f;
-        if (gm < o.M && gk < kend) v = o.p[(long)gm * o.rs + (long)gk * o.cs];
-        s[m][k] = v;
+        elem(o, tid + 256 * i, m, k);
+        const int gm = m0 + m, gk = k0 + k;
+        const bool ok = gm < o.M && gk < kend;
+        const float v = o.p[ok ? (long)gm * o.rs + (long)gk * o.cs : 0];          // (address always valid: no branch around the load)
+        r[i] = ok ? v : 0.f;
+    }
+}
+__device__ __forceinline__ void put(const Operand& o, const float (&r)[NI], float (*s)[LDK], int tid) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        int m, k;
+        elem(o, tid + 256 * i, m, k);
+        s[m][k] = r[i];
     }
 }
 
 // The 64 x 64 tile on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulate).  Wave w owns rows
 // [16w, 16w+16) x all 64 columns: acc[nt][r] = C[16w + 4*kq + r][16*nt + i] for lane (i = lane & 15, kq = lane >> 4).  The four MFMAs
-// of a 16-deep chunk take the k sets {4*kq + j : kq} (j = 0..3) -- any assignment of k to the slots is valid as long as both operands
+// of a 16-deep group take the k sets {4*kq + j : kq} (j = 0..3) -- any assignment of k to the slots is valid as long as both operands
 // use it -- so a lane's operands are ONE 16-byte LDS read per fragment (A[16w + i][4kq .. 4kq+3], B[16nt + i][4kq .. 4kq+3]).
 // The VALU form of this kernel (4 x 4 register tile per thread, 8 floats of LDS traffic per 16 FMAs) ran at 13 TFLOP/s.
 // rowsq (optional): |A row|^2 of the accumulator rows of this lane, i.e. rows 16w + 4*kq + r.
@@ -51,17 +65,27 @@ __device__ __forceinline__ void tile_gemm(const Operand& A, const Operand& B, in
     const int lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, kq = lane >> 4;
     float rs_part = 0.f;                          // this lane's share of |A[16w + i]|^2
+    float ra[NI], rb[NI];
+    fetch(A, m0, kbeg, kend, ra, tid);
+    fetch(B, n0, kbeg, kend, rb, tid);
     for (int k0 = kbeg; k0 < kend; k0 += TK) {
-        stage(A, m0, k0, kend, As, tid);
-        stage(B, n0, k0, kend, Bs, tid);
+        put(A, ra, As, tid);
+        put(B, rb, Bs, tid);
         __syncthreads();
-        const f4 a = *(const f4*)&As[16 * wave + i][4 * kq];
-        if (ROWSQ) rs_part += a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
+        if (k0 + TK < kend) {                     // in flight during the MFMAs below
+            fetch(A, m0, k0 + TK, kend, ra, tid);
+            fetch(B, n0, k0 + TK, kend, rb, tid);
+        }
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const f4 b = *(const f4*)&Bs[16 * nt + i][4 * kq];
+        for (int kk = 0; kk < TK; kk += 16) {
+            const f4 a = *(const f4*)&As[16 * wave + i][kk + 4 * kq];
+            if (ROWSQ) rs_part += a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc[nt], 0, 0, 0);
+            for (int nt = 0; nt < 4; ++nt) {
+                const f4 b = *(const f4*)&Bs[16 * nt + i][kk + 4 * kq];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc[nt], 0, 0, 0);
+            }
         }
         __syncthreads();
     }
