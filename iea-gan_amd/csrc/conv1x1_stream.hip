@@ -30,14 +30,19 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvArgs a, int 
     const int lr = lane & 15, lg = lane >> 4;
     const int H = a.H, W = a.W, HW = H * W;
     const long M = (long)a.N * HW;
-    const int n_base = blockIdx.y * NT * 16;
     const int Cin = a.Cin;
-    // XCD-aware order (blocks b and b + 8 share an XCD): every XCD walks one contiguous run of pixel groups
+    // XCD-aware order (blocks b and b + 8 share an XCD): every XCD walks one contiguous run of pixel groups.  The n-tile columns of a
+    // layer with more output channels than one block takes (gy > 1) are the FAST index of that order: the gy blocks that read the same
+    // pixels then run at the same time on the same XCD and share the activations through its L2 -- as blockIdx.y they were whole
+    // grid passes apart and every column streamed the input from memory again (5.7 GB per step over the 1x1 layers).
+    const int gy = (a.Cout + 16 * NT - 1) / (16 * NT);
     int bid = blockIdx.x;
     {
-        const int q = nblk / 8, r = nblk % 8, xcd = bid % 8;
+        const int tot = nblk * gy, q = tot / 8, r = tot % 8, xcd = bid % 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
     }
+    const int n_base = (bid % gy) * NT * 16;
+    bid /= gy;
     // a block stays inside ONE statistics group (event; gpe pixel groups, bpe blocks): a single flush at its end
     const int event = bid / bpe;
     const int g0 = event * gpe + (bid - event * bpe) * gpb;
@@ -283,7 +288,7 @@ static void stream_launch_one(const ConvArgs& a, hipStream_t st) {
     const int bpe = (gpe + gpb - 1) / gpb;
     const int nblk = bpe * n_events;
     CONV_PLAN_POINT(bpe, )
-    hipLaunchKernelGGL((conv1x1_stream_kernel<AFF, RELU, NT, KS, MT>), dim3(nblk, (a.Cout + 16 * NT - 1) / (16 * NT)), dim3(256), 0, st, a,
+    hipLaunchKernelGGL((conv1x1_stream_kernel<AFF, RELU, NT, KS, MT>), dim3(nblk * ((a.Cout + 16 * NT - 1) / (16 * NT))), dim3(256), 0, st, a,
                        gpb, gpe, nblk, bpe);
 }
 
@@ -312,6 +317,9 @@ static int stream_dispatch(const ConvArgs& a, hipStream_t st) {
 
 int conv1x1_stream_launch(const ConvArgs& a, hipStream_t st) {
     if (a.taps != 1 || a.src.rs != 0 || a.Cin > 128 || a.Kpad != ((a.Cin + 31) / 32) * 32) return 0;
+    // wide expansions go to conv1x1_tile (one LDS copy of 128 pixels serves 64 couts; here every 32 / 64 couts re-fetch the fragments):
+    // 128 -> 256 @32x96 52.9 -> 42.0 us, 128 -> 128 29.2 -> 24.8, 64 -> 256 37.1 -> 33.4 (32 -> 128 / 256 and 128 -> 64 stay: equal or slower there)
+    if ((a.Cin == 128 && a.Cout >= 128) || (a.Cin == 64 && a.Cout >= 256)) return 0;
     const long HW = (long)a.H * a.W, M = (long)a.N * HW;
     const int mt = (a.Cin <= 16 && a.Cout % 64 != 0) ? 4 : 2;
     const int gp = 4 * mt * 16;

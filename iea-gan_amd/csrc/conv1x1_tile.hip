@@ -50,9 +50,18 @@ __global__ __launch_bounds__(256, 3) void conv1x1_tile_kernel(ConvArgs a) {
     const int lr = lane & 15, lg = lane >> 4;
     const int H = a.H, W = a.W, HW = H * W;
     const long M = (long)a.N * HW;
-    const long m_blk = (long)blockIdx.x * 128;
+    // XCD-aware order with the n-tile column as the fast index (see conv1x1_stream.hip): the gy blocks that read the same 128 pixels
+    // run side by side on one XCD and share them through its L2
+    const int gy = a.Cout / (NT * 16);
+    int vid = blockIdx.x;
+    {
+        const int tot = gridDim.x, q = tot / 8, r = tot % 8, xcd = vid % 8;
+        vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + vid / 8;
+    }
+    const int bx = vid / gy;
+    const long m_blk = (long)bx * 128;
     const long m_base = m_blk + wave * 32;                    // this wave's 32 output pixels
-    const int n_base = blockIdx.y * NT * 16;
+    const int n_base = (vid % gy) * NT * 16;
     const int n_img = (int)(m_blk / HW);                      // AFF: the launcher guarantees HW % 128 == 0 (one image per block)
     if (AFF) stage_aff(aff_s, a.src, n_img, a.Cin);           // (the first barrier of the K loop publishes it)
     const float* affp = AFF ? aff_s : nullptr;
@@ -199,7 +208,7 @@ __global__ __launch_bounds__(256, 3) void conv1x1_tile_kernel(ConvArgs a) {
     if (a.stats != nullptr) {
         __syncthreads();          // every wave is done with its part of the epilogue buffer, which now serves as fold scratch
         const int event = (a.n_per_event > 0) ? (int)(m_blk / ((long)a.n_per_event * HW)) : 0;
-        stats_flush<NT>(a, s1, s2, n_base, red, epi, blockIdx.x, event);
+        stats_flush<NT>(a, s1, s2, n_base, red, epi, bx, event);
     }
 }
 
@@ -211,7 +220,7 @@ static int tile_dispatch(const ConvArgs& a, hipStream_t st) {
 #define TL(NTV, KCV)                                                                                                                    \
     {                                                                                                                                   \
         CONV_PLAN_POINT((int)(gx / n_events_t), 1)                                                                                      \
-        hipLaunchKernelGGL((conv1x1_tile_kernel<AFF, RELU, RS, NTV, KCV, BNB>), dim3(gx, a.Cout / (NTV * 16)), dim3(256), 0, st, a);     \
+        hipLaunchKernelGGL((conv1x1_tile_kernel<AFF, RELU, RS, NTV, KCV, BNB>), dim3(gx * (a.Cout / (NTV * 16))), dim3(256), 0, st, a);     \
         return 1;                                                                                                                       \
     }
 #define BY_KC(NTV)                      \

@@ -67,12 +67,16 @@ __global__ __launch_bounds__(NW * 64, (lds_image_bytes<CIN, NT, TH, TW, NW>() > 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 15, lg = lane >> 4;
     const int H = a.H, W = a.W;
-    const int n_base = blockIdx.y * NT * 16;
+    // XCD-aware order, the n-tile column (C = 128: four blocks of 32 couts per tile range) as the fast index: the blocks that read
+    // the same halos run side by side on one XCD and share them through its L2 (conv1x1_stream.hip)
+    const int gy = (a.Cout + NT * 16 - 1) / (NT * 16);
     int bid = blockIdx.x;
     {
-        const int q = nblk / 8, r = nblk % 8, xcd = bid % 8;
+        const int tot = nblk * gy, q = tot / 8, r = tot % 8, xcd = bid % 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
     }
+    const int n_base = (bid % gy) * NT * 16;
+    bid /= gy;
     const int event = bid / bpe;
     const int t0 = event * tpe + (bid - event * bpe) * tpb;
     const int t1 = min(t0 + tpb, (event + 1) * tpe);
@@ -311,7 +315,7 @@ static int lds_launch(const ConvArgs& a, hipStream_t st) {
             }                                                                                                                      \
             attr_set[full] = true;                                                                                                 \
         }                                                                                                                          \
-        hipLaunchKernelGGL(kern, dim3(nblk, gy), dim3(NWV * 64), lds, st, a, tiles_w, tiles_h, tpe, tpb, nblk, bpe);               \
+        hipLaunchKernelGGL(kern, dim3(nblk * gy), dim3(NWV * 64), lds, st, a, tiles_w, tiles_h, tpe, tpb, nblk, bpe);               \
         return 1;                                                                                                                  \
     }
     // C = 64 on the small maps (32x96: 240 tiles of 16x32, 16x48: 80): the 8-wave blocks would not even cover the CUs once -- the

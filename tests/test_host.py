@@ -380,3 +380,36 @@ def test_register_spill_ratchet_of_the_built_library():
     for f, (cnt, worst) in fam.items():
         assert f in allowed, (f, cnt, worst)
         assert cnt <= allowed[f][0] and worst <= allowed[f][1], (f, cnt, worst, allowed[f])
+
+
+def test_launched_kernels_are_spill_free_except_the_listed_ones():
+    """The kernels the benchmark step really LAUNCHES (names from the committed rocprofv3 kernel trace of the newest round) against the
+    code-object notes of the built library: scratch (spilled registers) only in the kernels listed here, and no more than listed."""
+    import csv
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import codeobj_notes as cn
+    so = os.path.join(root, "iea-gan_amd", "libieagan_hip.so")
+    traces = sorted(glob.glob(os.path.join(root, "profiles", "r0*_kernel_stats.csv")))
+    if not os.path.exists(so) or not traces:
+        pytest.skip("library or kernel trace missing")
+    rows = cn.kernels(so)
+    names = cn.demangle([r["name"] for r in rows])
+    launched = [r["Name"].strip() for r in csv.DictReader(open(traces[-1]))]
+    allowed = {"conv1x1_stream_kernel<false, false, 4, 2, 2>": 12, "conv1x1_bwd_kernel<64, 16, 0, true, 2, 64>": 36,
+               "conv1x1_bwd_kernel<16, 64, 0, true, 2, 64>": 20, "conv3x3_halo_kernel<true, true, 0, 2, 6, 32, false>": 44,
+               "conv3x3_halo_kernel<false, false, 0, 2, 6, 32, true>": 36, "conv3x3_halo_kernel<true, true, 1, 2, 6, 32, false>": 44}
+    matched, bad = 0, []
+    for key in launched:                    # (the trace keeps the first 140 characters of a name: prefix match)
+        ms = [r for n, r in zip(names, rows) if n.startswith(key) or r["name"].startswith(key)]
+        if not ms:
+            continue                        # not ours (ATen / rocBLAS / copy kernels)
+        matched += 1
+        worst = max(r["scratch"] for r in ms)
+        if worst:
+            short = re.sub(r"^void ", "", key).split("(")[0]
+            if short not in allowed or worst > allowed[short]:
+                bad.append((short, worst))
+    assert matched >= 100, matched
+    assert not bad, bad
