@@ -36,11 +36,28 @@ __global__ __launch_bounds__(256) void slin_fwd_kernel(SlinFwdArgs a) {
     const int K16 = (K + 15) & ~15, KS = K16 + 4;                    // rows zero-padded to whole 16-wide k groups
     const int m0 = blockIdx.x * 16;
     const int n0 = blockIdx.y * 64 + wave * 16;
-    for (int idx = threadIdx.x; idx < 16 * (K16 >> 2); idx += 256) {
-        const int r = idx / (K16 >> 2), c4 = idx - r * (K16 >> 2);
-        f32x4v v = {0.f, 0.f, 0.f, 0.f};
-        if (m0 + r < M && c4 * 4 < K) v = *(const f32x4v*)(a.X + (long)(m0 + r) * K + c4 * 4);
-        *(f32x4v*)(xs + r * KS + c4 * 4) = v;
+    {
+        // the 16 x K16 input rows -> LDS in batches of 8 unconditional 16-byte loads per thread (row / column clamped, zeroed by a select
+        // afterwards): as a rolled load -> store loop this was one memory round trip per 4 KB, 24 of them in a row at K = 1536
+        const int c4n = K16 >> 2, tot = 16 * c4n;
+        for (int b0 = 0; b0 < tot; b0 += 8 * 256) {
+            f32x4v v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = min(b0 + u * 256 + (int)threadIdx.x, tot - 1);
+                const int r = idx / c4n, c4 = idx - r * c4n;
+                v[u] = *(const f32x4v*)(a.X + (long)min(m0 + r, M - 1) * K + min(c4 * 4, K - 4));
+                if (m0 + r >= M || c4 * 4 >= K) v[u] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = b0 + u * 256 + (int)threadIdx.x;
+                if (idx < tot) {
+                    const int r = idx / c4n, c4 = idx - r * c4n;
+                    *(f32x4v*)(xs + r * KS + c4 * 4) = v[u];
+                }
+            }
+        }
     }
     __syncthreads();
     if (a.ln_g != nullptr) {                     // LayerNorm (biased variance, eps inside the root) on rows wave*4 .. wave*4+3
