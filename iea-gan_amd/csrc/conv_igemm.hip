@@ -238,13 +238,24 @@ __global__ __launch_bounds__(256, ((CIN >= 64 && PF == 0) ? 2 : (CIN == 16 ? 4 :
     const int t1 = min(t0 + tpb, (event + 1) * tpe);
     const bool col_ok = (n_base + (NT - 1) * 16 + lr) < a.Cout;
 
-    if (PF > 0) {   // weights -> LDS once per block
-        const int wchunks = a.Kpad >> 3;
-        for (int idx = threadIdx.x; idx < NT * 16 * wchunks; idx += 256) {
-            const int row = idx / wchunks, kc = idx - row * wchunks;
-            bf16x8 v = zero8();
-            if (n_base + row < a.Cout) v = *(const bf16x8*)((const bf16*)a.w + (long)(n_base + row) * a.Kpad + kc * 8);
-            *(bf16x8*)(smem_all + row * WS + kc * 16) = v;
+    if (PF > 0) {   // weights -> LDS once per block: compile-time trip count (Kpad = 9 * CIN rounded up to 32), all loads of a batch first
+        constexpr int wchunks = (((9 * (CIN > 0 ? CIN : 16) + 31) / 32) * 32) >> 3;
+        constexpr int WIT = (NT * 16 * wchunks + 255) / 256, WB = 6;
+#pragma unroll
+        for (int b0 = 0; b0 < WIT; b0 += WB) {
+            bf16x8 wv[WB];
+#pragma unroll
+            for (int j = 0; j < WB; ++j) {
+                const int idx = min((int)threadIdx.x + (b0 + j) * 256, NT * 16 * wchunks - 1);
+                const int row = idx / wchunks, kc = idx - row * wchunks;
+                wv[j] = *(const bf16x8*)((const bf16*)a.w + (long)min(n_base + row, a.Cout - 1) * a.Kpad + kc * 8);
+                if (n_base + row >= a.Cout) wv[j] = zero8();
+            }
+#pragma unroll
+            for (int j = 0; j < WB; ++j) {
+                const int idx = threadIdx.x + (b0 + j) * 256;
+                if (b0 + j < WIT && idx < NT * 16 * wchunks) *(bf16x8*)(smem_all + (idx / wchunks) * WS + (idx % wchunks) * 16) = wv[j];
+            }
         }
     }
     __shared__ __attribute__((aligned(32))) float aff_s[AFF ? 2 * AFF_MAXC : 8];
