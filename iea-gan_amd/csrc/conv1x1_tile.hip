@@ -239,7 +239,10 @@ int conv1x1_tile_launch(const ConvArgs& a, hipStream_t st) {
     if (a.taps != 1 || (a.src.rs != 0 && a.src.rs != 2) || a.Cout % 32 != 0 || a.Cin % 8 != 0) return 0;
     if (!(a.Cin <= 32 || a.Cin == 64 || a.Cin % 128 == 0) || a.Kpad != ((a.Cin + 31) / 32) * 32) return 0;
     const long HW = (long)a.H * a.W, M = (long)a.N * HW;
-    if (M < 16384) return 0;                                   // tiny maps: conv_gather's split-K form covers more CUs
+    // tiny maps stay with conv_gather's split-K form (4x12: 512 -> 128 7.3 us there, 14.0 here); from 8x24 up this kernel wins even with 60
+    // pixel blocks (8x24: 256 -> 256 19.7 -> 8.7 us, pooled source 40.3 -> 13.3; 128 -> 512 13.2 -> 9.4), pooled sources already at 4x12 (13.0 -> 8.5)
+    if (M < (a.src.rs == 2 ? 1024 : 4096)) return 0;
+    if (M < 16384 && a.Cin > 256) return 0;                    // four serial K chunks on 120 blocks: in-step 17.7 -> 26.5 us for 512 -> 128 at 8x24
     const bool aff = a.src.scale != nullptr, relu = a.src.relu != 0;
     if (aff && (HW % 128 != 0 || a.Cin > AFF_MAXC)) return 0;  // one image (one BatchNorm table) per 128-pixel block
     if (a.bnb_scale != nullptr) {
