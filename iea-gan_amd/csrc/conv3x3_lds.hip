@@ -318,10 +318,11 @@ static int lds_launch(const ConvArgs& a, hipStream_t st) {
         hipLaunchKernelGGL(kern, dim3(nblk * gy), dim3(NWV * 64), lds, st, a, tiles_w, tiles_h, tpe, tpb, nblk, bpe);               \
         return 1;                                                                                                                  \
     }
-    // C = 64 on the small maps (32x96: 240 tiles of 16x32, 16x48: 80): the 8-wave blocks would not even cover the CUs once -- the
-    // 4-wave 8x16 form with 32 output channels per block (60 KB of LDS: two blocks per CU) gives 8x as many blocks
+    // C = 64 on the smallest maps (16x48: 80 tile pairs): the 8-wave blocks would cover a third of the CUs -- the 4-wave 8x16 form with
+    // 32 output channels per block (60 KB of LDS: two blocks per CU) gives 8x as many blocks (16x48: 9.4 vs 11.9 us; 32x96 is better off with
+    // the 8-wave form since it prefetches: 20.3 -> 19.2 us)
     if (a.Cin == 64 && a.Cout % 64 == 0 && a.H >= 8 && a.W >= 16 &&
-        (long)a.N * ((a.H + 15) / 16) * ((a.W + 31) / 32) * (a.Cout / 64) < 400) LDS_LAUNCH(64, 2, 8, 16, 4)
+        (long)a.N * ((a.H + 15) / 16) * ((a.W + 31) / 32) * (a.Cout / 64) < 100) LDS_LAUNCH(64, 2, 8, 16, 4)
     if (a.Cin == 64 && a.Cout % 64 == 0 && a.H >= 16 && a.W >= 32) LDS_LAUNCH(64, 4, 8, 32, 8)
     if (a.Cin == 128 && a.Cout % 32 == 0 && a.H >= 8 && a.W >= 16) LDS_LAUNCH(128, 2, 8, 16, 4)
 #undef LDS_LAUNCH
