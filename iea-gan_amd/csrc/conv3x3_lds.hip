@@ -396,12 +396,14 @@ __global__ __launch_bounds__(NW * 64, 2) void conv3x3_lds_fp8_kernel(ConvArgs a,
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 15, lg = lane >> 4;
     const int H = a.H, W = a.W;
-    const int n_base = blockIdx.y * NT * 16;
+    const int gy = (a.Cout + NT * 16 - 1) / (NT * 16);         // n-tile column = fast index of the XCD-aware order (see the bf16 kernel)
     int bid = blockIdx.x;
     {
-        const int q = nblk / 8, r = nblk % 8, xcd = bid % 8;
+        const int tot = nblk * gy, q = tot / 8, r = tot % 8, xcd = bid % 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
     }
+    const int n_base = (bid % gy) * NT * 16;
+    bid /= gy;
     const int event = bid / bpe;
     const int t0 = event * tpe + (bid - event * bpe) * tpb;
     const int t1 = min(t0 + tpb, (event + 1) * tpe);
@@ -686,10 +688,10 @@ static int lds_fp8_launch(const ConvArgs& a, hipStream_t st) {
         const size_t halo = (size_t)(THV + 2) * (TWV + 2) * CINV, epi = (size_t)NWV * EpiLds<NTV>::FLOATS * 4;                     \
         const size_t lds = (size_t)NTV * 16 * 9 * CINV + (halo > epi ? halo : epi);                                                \
         if (a.flags & IEAGAN_CONV_FP8_NOSCALE)                                                                                     \
-            hipLaunchKernelGGL((conv3x3_lds_fp8_kernel<AFF, RELU, RS, CINV, NTV, THV, TWV, NWV, BNB, false>), dim3(nblk, gy), dim3(NWV * 64), lds, \
+            hipLaunchKernelGGL((conv3x3_lds_fp8_kernel<AFF, RELU, RS, CINV, NTV, THV, TWV, NWV, BNB, false>), dim3(nblk * gy), dim3(NWV * 64), lds, \
                                st, a, tiles_w, tiles_h, tpe, tpb, nblk, bpe);                                                      \
         else                                                                                                                       \
-            hipLaunchKernelGGL((conv3x3_lds_fp8_kernel<AFF, RELU, RS, CINV, NTV, THV, TWV, NWV, BNB, true>), dim3(nblk, gy), dim3(NWV * 64), lds, \
+            hipLaunchKernelGGL((conv3x3_lds_fp8_kernel<AFF, RELU, RS, CINV, NTV, THV, TWV, NWV, BNB, true>), dim3(nblk * gy), dim3(NWV * 64), lds, \
                                st, a, tiles_w, tiles_h, tpe, tpb, nblk, bpe);                                                      \
         return 1;                                                                                                                  \
     }
