@@ -228,10 +228,14 @@ def test_ws_kernel_affine_prologue_and_event_statistics(dev):
     (32, 64, 128, 384, 4, True, False, "cat", False, 1),     # residual A on channels [0, 32) + residual B on [32, 64)
     (128, 32, 64, 192, 12, False, True, None, False, 1),     # four k-steps
     (64, 128, 64, 192, 12, True, True, "pool", False, 1),    # grid.y = 2, double-resolution shortcut (2x2 average)
+    (256, 256, 8, 24, 40, False, False, None, False, 1),     # conv1x1_tile on an 8x24 map (60 pixel blocks x 4 n-tile columns, round 4)
+    (128, 256, 32, 96, 8, False, True, "same", True, 1),     # wide expansion: conv1x1_tile instead of conv1x1_stream, 4 columns share the pixels
+    (64, 256, 32, 96, 8, True, True, None, False, 2),        # Cin = 64 / Cout = 256 with the BatchNorm prologue, two events
 ])
 def test_streaming_1x1_agrees_with_gather(dev, Cin, Cout, Hh, Ww, N, aff, relu, res, mask, events):
-    """conv1x1_stream (prefetched operands, weights in registers, per-block statistics) against conv_gather (one tile per block) on
-    identical operands: same outputs bit for bit (same MFMA order per output) and the same per-event statistics."""
+    """conv1x1_stream (prefetched operands, weights in registers, per-block statistics) and conv1x1_tile (LDS-tiled; the last three cases)
+    against conv_gather (one tile per block) on identical operands: same outputs bit for bit (same MFMA order per output) and the same
+    per-event statistics."""
     import _hip, ops
     torch.manual_seed(21)
     x = torch.randn(N, Hh, Ww, Cin, device=dev).to(BF)
