@@ -391,7 +391,10 @@ def test_launched_kernels_are_spill_free_except_the_listed_ones():
     sys.path.insert(0, os.path.join(root, "tools"))
     import codeobj_notes as cn
     so = os.path.join(root, "iea-gan_amd", "libieagan_hip.so")
-    traces = sorted(glob.glob(os.path.join(root, "profiles", "r0*_kernel_stats.csv")))
+    def newest_last(path):                  # rNN_ (end of round) after rNNa_ / rNN_mid_ (mid-round sets)
+        m = re.match(r"r(\d+)([a-z]*)_(mid_|final_|baseline_)?kernel_stats", os.path.basename(path))
+        return (int(m.group(1)), m.group(2) == "" and m.group(3) in (None, "final_"), m.group(2), m.group(3) or "") if m else (-1, False, "", "")
+    traces = sorted(glob.glob(os.path.join(root, "profiles", "r0*_kernel_stats.csv")), key=newest_last)
     if not os.path.exists(so) or not traces:
         pytest.skip("library or kernel trace missing")
     rows = cn.kernels(so)
