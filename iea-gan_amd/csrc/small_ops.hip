@@ -35,11 +35,41 @@ __global__ __launch_bounds__(256) void rrm_attn_fwd_kernel(const float* __restri
     const int h = blockIdx.x, b = blockIdx.y;
     const int E3 = Hh * 3 * hd;
     const float* base = qkv + (long)b * S * E3 + h * 3 * hd;
-    for (int idx = threadIdx.x; idx < S * hd; idx += 256) {
-        const int s = idx / hd, d = idx - s * hd;
-        q[s * LD + d] = base[(long)s * E3 + d];
-        k[s * LD + d] = base[(long)s * E3 + hd + d];
-        v[s * LD + d] = base[(long)s * E3 + 2 * hd + d];
+    // q, k, v of this head -> LDS.  (hd % 4 == 0: 16-byte loads, four per operand and thread in flight -- as a rolled scalar loop the 4 blocks
+    // of a launch spent 20 serial memory round trips here, two thirds of the kernel)
+    if ((hd & 3) == 0) {
+        const int hd4 = hd >> 2, tot = S * hd4;
+        for (int b0 = 0; b0 < tot; b0 += 4 * 256) {
+            f32x4 rq[4], rk[4], rv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = min(b0 + u * 256 + (int)threadIdx.x, tot - 1);
+                const int s = idx / hd4, d4 = idx - s * hd4;
+                const float* p = base + (long)s * E3 + d4 * 4;
+                rq[u] = *(const f32x4*)p;
+                rk[u] = *(const f32x4*)(p + hd);
+                rv[u] = *(const f32x4*)(p + 2 * hd);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = b0 + u * 256 + (int)threadIdx.x;
+                if (idx >= tot) continue;
+                const int s = idx / hd4, d4 = idx - s * hd4;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    q[s * LD + d4 * 4 + c] = rq[u][c];
+                    k[s * LD + d4 * 4 + c] = rk[u][c];
+                    v[s * LD + d4 * 4 + c] = rv[u][c];
+                }
+            }
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < S * hd; idx += 256) {
+            const int s = idx / hd, d = idx - s * hd;
+            q[s * LD + d] = base[(long)s * E3 + d];
+            k[s * LD + d] = base[(long)s * E3 + hd + d];
+            v[s * LD + d] = base[(long)s * E3 + 2 * hd + d];
+        }
     }
     __syncthreads();
     const float scale = rsqrtf((float)hd);
@@ -87,15 +117,53 @@ __global__ __launch_bounds__(256) void rrm_attn_bwd_kernel(const float* __restri
     const int h = blockIdx.x, b = blockIdx.y;
     const int E3 = Hh * 3 * hd, E = Hh * hd;
     const float* base = qkv + (long)b * S * E3 + h * 3 * hd;
-    for (int idx = threadIdx.x; idx < S * hd; idx += 256) {
-        const int s = idx / hd, d = idx - s * hd;
-        q[s * LD + d] = base[(long)s * E3 + d];
-        k[s * LD + d] = base[(long)s * E3 + hd + d];
-        v[s * LD + d] = base[(long)s * E3 + 2 * hd + d];
-        go[s * LD + d] = dout[((long)b * S + s) * E + h * hd + d];
+    if ((hd & 3) == 0) {                            // 16-byte loads, a batch of them in flight (see the forward kernel)
+        const int hd4 = hd >> 2, tot = S * hd4;
+        for (int b0 = 0; b0 < tot; b0 += 4 * 256) {
+            f32x4 rq[4], rk[4], rv[4], rg[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = min(b0 + u * 256 + (int)threadIdx.x, tot - 1);
+                const int s = idx / hd4, d4 = idx - s * hd4;
+                const float* p = base + (long)s * E3 + d4 * 4;
+                rq[u] = *(const f32x4*)p;
+                rk[u] = *(const f32x4*)(p + hd);
+                rv[u] = *(const f32x4*)(p + 2 * hd);
+                rg[u] = *(const f32x4*)(dout + ((long)b * S + s) * E + h * hd + d4 * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = b0 + u * 256 + (int)threadIdx.x;
+                if (idx >= tot) continue;
+                const int s = idx / hd4, d4 = idx - s * hd4;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    q[s * LD + d4 * 4 + c] = rq[u][c];
+                    k[s * LD + d4 * 4 + c] = rk[u][c];
+                    v[s * LD + d4 * 4 + c] = rv[u][c];
+                    go[s * LD + d4 * 4 + c] = rg[u][c];
+                }
+            }
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < S * hd; idx += 256) {
+            const int s = idx / hd, d = idx - s * hd;
+            q[s * LD + d] = base[(long)s * E3 + d];
+            k[s * LD + d] = base[(long)s * E3 + hd + d];
+            v[s * LD + d] = base[(long)s * E3 + 2 * hd + d];
+            go[s * LD + d] = dout[((long)b * S + s) * E + h * hd + d];
+        }
     }
     const float* ai = att_in + ((long)b * Hh + h) * S * S;
-    for (int idx = threadIdx.x; idx < S * S; idx += 256) att[idx] = ai[idx];
+    {
+        const int tot = S * S;                      // (S <= 64: at most 16 values per thread, all requested before the first store)
+        float ra[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) ra[u] = ai[min(u * 256 + (int)threadIdx.x, tot - 1)];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (u * 256 + (int)threadIdx.x < tot) att[u * 256 + threadIdx.x] = ra[u];
+    }
     __syncthreads();
     for (int idx = threadIdx.x; idx < S * S; idx += 256) {    // d att_ij = dout_i . v_j
         const int i = idx / S, j = idx - i * S;
