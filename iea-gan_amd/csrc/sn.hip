@@ -220,8 +220,8 @@ __device__ __forceinline__ float sn_dot(const float* __restrict__ gsn, const flo
         float gv[UB], wv[UB];
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
-            const long e = min(e0 + u * stride, end - 1);
-            const int o = (int)(e / in), i = (int)(e % in);
+            const unsigned e = (unsigned)min(e0 + u * stride, end - 1);      // (a layer has < 2^31 elements: 32-bit division)
+            const int o = (int)(e / (unsigned)in), i = (int)(e - (unsigned)o * (unsigned)in);
             gv[u] = gsn_at(gsn, kind, o, i, out, in, taps, cin, kpad);
             wv[u] = W[e];
         }
@@ -240,8 +240,8 @@ __device__ __forceinline__ void sn_apply(const float* __restrict__ gsn, int kind
         float gv[UB], uv[UB], vv[UB], dv[UB];
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
-            const long e = min(e0 + u * stride, end - 1);
-            const int o = (int)(e / in), i = (int)(e % in);
+            const unsigned e = (unsigned)min(e0 + u * stride, end - 1);
+            const int o = (int)(e / (unsigned)in), i = (int)(e - (unsigned)o * (unsigned)in);
             gv[u] = gsn_at(gsn, kind, o, i, out, in, taps, cin, kpad);
             uv[u] = u_[o];
             vv[u] = v_[i];
