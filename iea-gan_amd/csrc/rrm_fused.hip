@@ -240,16 +240,48 @@ __global__ __launch_bounds__(256) void slin_bwd_kernel(SlinBwdArgs a) {
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) acc[jj] = (f32x4v){0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
-    for (int t = 0; t < ((M + 3) >> 2); ++t) {
-        const int m = 4 * t + q;
-        const float ga = nok ? slin_dy(a, m, n0 + i) : 0.f;
-        bsum += ga;
-        if (a.dW == nullptr) continue;
+    {
+        // TB reduction steps (4 rows each) per batch, every load unconditional (row / column clamped, zeroed by selects): the rolled loop was one
+        // memory round trip per step, M / 4 in a row
+        constexpr int TB = 4;
+        const int nsteps = (M + 3) >> 2;
+        const bool masked = a.Ymask != nullptr, plain = a.Xn != nullptr, want_w = a.dW != nullptr;
+        const float* xsrc = plain ? a.Xn : a.xhat;
+        const int ncol = nok ? n0 + i : 0;
+        int kc[4];
+        float lg[4], lb[4];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-            const int k = k0 + 16 * jj + i;
-            const float xb = (k < K) ? slin_xn(a, m, k) : 0.f;
-            acc[jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga, xb, acc[jj], 0, 0, 0);
+            kc[jj] = min(k0 + 16 * jj + i, K - 1);
+            lg[jj] = (!plain && want_w) ? a.ln_g[kc[jj]] : 1.f;
+            lb[jj] = (!plain && want_w) ? a.ln_b[kc[jj]] : 0.f;
+        }
+        for (int t0 = 0; t0 < nsteps; t0 += TB) {
+            float gv[TB], yv[TB], xv[TB][4];
+#pragma unroll
+            for (int u = 0; u < TB; ++u) {
+                const int mc = min(4 * (t0 + u) + q, M - 1);
+                gv[u] = a.dY[(long)mc * N + ncol];
+                yv[u] = masked ? a.Ymask[(long)mc * N + ncol] : 1.f;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) xv[u][jj] = want_w ? xsrc[(long)mc * K + kc[jj]] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < TB; ++u) {
+                if (t0 + u >= nsteps) break;            // wave-uniform
+                const int m = 4 * (t0 + u) + q;
+                float ga = (nok && m < M) ? gv[u] : 0.f;
+                if (masked && !(yv[u] > 0.f)) ga = 0.f;
+                bsum += ga;
+                if (!want_w) continue;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int k = k0 + 16 * jj + i;
+                    float xb = plain ? xv[u][jj] : xv[u][jj] * lg[jj] + lb[jj];
+                    if (k >= K || m >= M) xb = 0.f;
+                    acc[jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga, xb, acc[jj], 0, 0, 0);
+                }
+            }
         }
     }
     if (a.dW != nullptr) {
