@@ -29,7 +29,7 @@ struct SlinFwdArgs {
 };
 
 __global__ __launch_bounds__(256) void slin_fwd_kernel(SlinFwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float xs[];       // [16][K + 4]
+    extern __shared__ __attribute__((aligned(16))) float xs[];       // [16][K16 + 4], then (LayerNorm prologue) gamma [K16] and beta [K16]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, kq = lane >> 4;
     const int M = a.M, K = a.K, N = a.N;
@@ -59,6 +59,24 @@ __global__ __launch_bounds__(256) void slin_fwd_kernel(SlinFwdArgs a) {
             }
         }
     }
+    float* lgs = xs + 16 * KS;                   // gamma / beta of the LayerNorm prologue: staged once (read per row and column below -- as
+    float* lbs = lgs + K16;                      // global loads inside the row loop they were a memory round trip per 64 columns and row)
+    if (a.ln_g != nullptr) {
+        constexpr int LB = 6;                    // K <= 1536: 256 threads x 6
+        float rg[LB], rb[LB];
+#pragma unroll
+        for (int u = 0; u < LB; ++u) {
+            const int c = min(u * 256 + (int)threadIdx.x, K - 1);
+            rg[u] = a.ln_g[c];
+            rb[u] = a.ln_b[c];
+        }
+#pragma unroll
+        for (int u = 0; u < LB; ++u) {
+            const int c = u * 256 + (int)threadIdx.x;
+            if (c < K) { lgs[c] = rg[u]; lbs[c] = rb[u]; }
+        }
+        for (int c = LB * 256 + threadIdx.x; c < K; c += 256) { lgs[c] = a.ln_g[c]; lbs[c] = a.ln_b[c]; }      // (K > 1536: not in this network)
+    }
     __syncthreads();
     if (a.ln_g != nullptr) {                     // LayerNorm (biased variance, eps inside the root) on rows wave*4 .. wave*4+3
 #pragma unroll 1
@@ -77,7 +95,7 @@ __global__ __launch_bounds__(256) void slin_fwd_kernel(SlinFwdArgs a) {
             for (int c = lane; c < K; c += 64) {
                 const float xh = (xs[row * KS + c] - mean) * rstd;
                 if (save) a.xhat[(long)(m0 + row) * K + c] = xh;
-                xs[row * KS + c] = xh * a.ln_g[c] + a.ln_b[c];
+                xs[row * KS + c] = xh * lgs[c] + lbs[c];
             }
             if (save && lane == 0) a.rstd[m0 + row] = rstd;
         }
@@ -398,7 +416,7 @@ extern "C" int ieagan_slin_fwd(const float* X, const float* W, const float* b, c
     SlinFwdArgs a{X, W, b, R, Y, ln_g, ln_b, xhat, rstd, M, K, N, relu, eps};
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof("slin_fwd", 2.0 * M * (double)K * N, 4.0 * ((double)M * K + (double)N * K + (double)M * N), st);
-    const size_t lds = (size_t)16 * (((K + 15) & ~15) + 4) * 4;
+    const size_t lds = (size_t)16 * (((K + 15) & ~15) + 4) * 4 + (ln_g != nullptr ? (size_t)2 * ((K + 15) & ~15) * 4 : 0);
     hipLaunchKernelGGL(slin_fwd_kernel, dim3((M + 15) / 16, (N + 63) / 64), dim3(256), lds, st, a);
     CHECK_LAUNCH("slin_fwd");
     return 0;
