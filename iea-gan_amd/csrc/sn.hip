@@ -46,7 +46,18 @@ __global__ __launch_bounds__(256) void sn_phase1_kernel(const long* __restrict__
     const int r1 = min(row0 + SN_ROWS, out);
     for (int i = threadIdx.x; i < in; i += 256) {
         float s = 0.f;
-        for (int o = row0; o < r1; ++o) s += u[o] * W[(long)o * in + i];
+        for (int o0 = row0; o0 < r1; o0 += 8) {      // eight rows in flight (clamped, masked): same order of additions as the plain loop
+            float w[8], uu[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int o = min(o0 + k, r1 - 1);
+                w[k] = W[(long)o * in + i];
+                uu[k] = u[o];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (o0 + k < r1) s += uu[k] * w[k];
+        }
         dst[i] = s;
     }
 }
@@ -102,7 +113,18 @@ __global__ __launch_bounds__(256) void sn_phase2_kernel(const long* __restrict__
     float sq = 0.f;
     for (int o = row0 + wave; o < r1; o += 4) {
         float s = 0.f;
-        for (int i = lane; i < in; i += 64) s += W[(long)o * in + i] * (vraw[i] * inv);
+        for (int i0 = lane; i0 < in; i0 += 6 * 64) {   // six columns per lane in flight (clamped, masked), same order of additions
+            float w[6], vv[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int i = min(i0 + k * 64, in - 1);
+                w[k] = W[(long)o * in + i];
+                vv[k] = vraw[i];
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                if (i0 + k * 64 < in) s += w[k] * (vv[k] * inv);
+        }
         s = wave_sum(s);
         sq += s * s;
         if (lane == 0) c[8 + out + 2 * in + o] = s;            // t[o]; phase 3 turns it into u'
@@ -143,26 +165,46 @@ __global__ __launch_bounds__(256) void sn_phase3_kernel(const long* __restrict__
         if (training) params[L[F_SV]] = sigma;
     }
     const int rows = r1 - row0;
+    // The packing loops below: 8 elements per thread per batch, every weight load (index clamped to a valid element) issued before the first
+    // store.  Rolled, each element was a dependent load -> convert -> store round trip: 144 in a row for a C = 128 3x3 layer, 110 us for the
+    // phase although it moves 93 MB.  (A block's share of a layer has < 2^31 elements: 32-bit index arithmetic.)
+    auto batched = [&](int total, auto&& src_index, auto&& put) {
+        for (int e0 = threadIdx.x; e0 < total; e0 += 8 * 256) {
+            float w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w[u] = W[src_index(min(e0 + u * 256, total - 1))];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (e0 + u * 256 < total) put(e0 + u * 256, w[u]);
+        }
+    };
     if (kind == 0) {
         float* dst = (float*)(pack + L[F_PACK]);
-        for (long e = threadIdx.x; e < (long)rows * in; e += 256) dst[(long)row0 * in + e] = W[(long)row0 * in + e] * isg;
+        batched(rows * in, [&](int e) { return (long)row0 * in + e; }, [&](int e, float w) { dst[(long)row0 * in + e] = w * isg; });
     } else if (kind == 1) {
         bf16* p1 = (bf16*)(pack + L[F_PACK]);
         bf16* p2 = (bf16*)(pack + L[F_PACK2]);
-        for (long e = threadIdx.x; e < (long)rows * kpad; e += 256) {       // forward pack (incl. zero padding)
-            const int o = row0 + (int)(e / kpad), k = (int)(e % kpad);
-            float v = 0.f;
-            if (k < taps * cin) {
-                const int tap = k / cin, ci = k - tap * cin;
-                v = W[(long)o * in + ci * taps + tap] * isg;
-            }
-            p1[(long)o * kpad + k] = f2bf(v);
-        }
-        for (long e = threadIdx.x; e < (long)rows * in; e += 256) {         // dgrad pack: o fastest -> the 2-byte stores of
-            const int o = row0 + (int)(e % rows), i = (int)(e / rows);      // a wave are contiguous runs (the reads hit in cache)
-            const int ci = i / taps, tap = i - ci * taps;
-            p2[(long)ci * kpad2 + (taps - 1 - tap) * out + o] = f2bf(W[(long)o * in + i] * isg);
-        }
+        const int kreal = taps * cin;
+        batched(rows * kpad,                                                 // forward pack (incl. zero padding)
+                [&](int e) {
+                    const int r = e / kpad, k = min(e - r * kpad, kreal - 1);
+                    const int tap = k / cin, ci = k - tap * cin;
+                    return (long)(row0 + r) * in + ci * taps + tap;
+                },
+                [&](int e, float w) {
+                    const int r = e / kpad, k = e - r * kpad;
+                    p1[(long)(row0 + r) * kpad + k] = f2bf(k < kreal ? w * isg : 0.f);
+                });
+        batched(rows * in,                                                   // dgrad pack: o fastest -> the 2-byte stores of a wave are
+                [&](int e) {                                                 // contiguous runs (the reads hit in cache)
+                    const int i = e / rows, o = row0 + (e - i * rows);
+                    return (long)o * in + i;
+                },
+                [&](int e, float w) {
+                    const int i = e / rows, o = row0 + (e - i * rows);
+                    const int ci = i / taps, tap = i - ci * taps;
+                    p2[(long)ci * kpad2 + (taps - 1 - tap) * out + o] = f2bf(w * isg);
+                });
         // zero padding columns of the dgrad pack: k' in [taps*out, kpad2), written by the block that owns row 0
         if (row0 == 0 && kpad2 > taps * out) {
             const int padw = kpad2 - taps * out;
