@@ -21,6 +21,7 @@ enum { F_W = 0, F_U, F_SV, F_OUT, F_IN, F_TAPS, F_CIN, F_KIND, F_CTX, F_PACK, F_
 // ctx layout per layer (fp32, at F_CTX): [0] sigma, [8 .. 8+out) u', [8+out .. 8+out+in) v_raw,
 //   [8+out+in .. 8+out+2*in) v, [8+out+2*in .. 8+2*out+2*in) t = W v
 #define SN_ROWS 32
+#define SN_P3SPLIT 4
 
 __device__ __forceinline__ float block_sum(float v, float* red) {
     v = wave_sum(v);
@@ -139,8 +140,11 @@ __global__ __launch_bounds__(256) void sn_phase2_kernel(const long* __restrict__
 __global__ __launch_bounds__(256) void sn_phase3_kernel(const long* __restrict__ tab, const int* __restrict__ blocks,
                                                         float* __restrict__ params, float* __restrict__ ctx, const float* __restrict__ part,
                                                         char* __restrict__ pack, float eps, int training) {
-    const long* L = tab + (long)blocks[2 * blockIdx.x] * SN_FIELDS;
-    const int row0 = blocks[2 * blockIdx.x + 1];
+    // SN_P3SPLIT blocks share one (layer, 32-row chunk) of the block table: the packing loops below are the long part of this phase (a C = 128
+    // 3x3 chunk is 74 K elements), every block takes a contiguous 1 / SN_P3SPLIT of each loop; sigma is recomputed by each (a 24-long fold)
+    const int bix = blockIdx.x / SN_P3SPLIT, part_ix = blockIdx.x % SN_P3SPLIT;
+    const long* L = tab + (long)blocks[2 * bix] * SN_FIELDS;
+    const int row0 = blocks[2 * bix + 1];
     const int out = (int)L[F_OUT], in = (int)L[F_IN], taps = (int)L[F_TAPS], cin = (int)L[F_CIN], kind = (int)L[F_KIND];
     const int kpad = (int)L[F_KPAD], kpad2 = (int)L[F_KPAD2];
     const float* W = params + L[F_W];
@@ -155,12 +159,14 @@ __global__ __launch_bounds__(256) void sn_phase3_kernel(const long* __restrict__
     const float sigma = tt / un;
     const float isg = 1.f / sigma;
     const int r1 = min(row0 + SN_ROWS, out);
-    for (int o = row0 + threadIdx.x; o < r1; o += 256) {
-        const float un_o = tvec[o] / un;
-        c[8 + o] = un_o;
-        if (training) params[L[F_U] + o] = un_o;
+    if (part_ix == 0) {
+        for (int o = row0 + threadIdx.x; o < r1; o += 256) {
+            const float un_o = tvec[o] / un;
+            c[8 + o] = un_o;
+            if (training) params[L[F_U] + o] = un_o;
+        }
     }
-    if (row0 == 0 && threadIdx.x == 0) {
+    if (row0 == 0 && part_ix == 0 && threadIdx.x == 0) {
         c[0] = sigma;
         if (training) params[L[F_SV]] = sigma;
     }
@@ -168,8 +174,10 @@ __global__ __launch_bounds__(256) void sn_phase3_kernel(const long* __restrict__
     // The packing loops below: 8 elements per thread per batch, every weight load (index clamped to a valid element) issued before the first
     // store.  Rolled, each element was a dependent load -> convert -> store round trip: 144 in a row for a C = 128 3x3 layer, 110 us for the
     // phase although it moves 93 MB.  (A block's share of a layer has < 2^31 elements: 32-bit index arithmetic.)
-    auto batched = [&](int total, auto&& src_index, auto&& put) {
-        for (int e0 = threadIdx.x; e0 < total; e0 += 8 * 256) {
+    auto batched = [&](int total_all, auto&& src_index, auto&& put) {
+        const int per = (total_all + SN_P3SPLIT - 1) / SN_P3SPLIT;
+        const int total = min(total_all, (part_ix + 1) * per);              // this block's share: [part_ix * per, total)
+        for (int e0 = part_ix * per + threadIdx.x; e0 < total; e0 += 8 * 256) {
             float w[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) w[u] = W[src_index(min(e0 + u * 256, total - 1))];
@@ -206,12 +214,12 @@ __global__ __launch_bounds__(256) void sn_phase3_kernel(const long* __restrict__
                     p2[(long)ci * kpad2 + (taps - 1 - tap) * out + o] = f2bf(w * isg);
                 });
         // zero padding columns of the dgrad pack: k' in [taps*out, kpad2), written by the block that owns row 0
-        if (row0 == 0 && kpad2 > taps * out) {
+        if (row0 == 0 && part_ix == 0 && kpad2 > taps * out) {
             const int padw = kpad2 - taps * out;
             for (long e = threadIdx.x; e < (long)cin * padw; e += 256)
                 p2[(e / padw) * kpad2 + taps * out + (e % padw)] = f2bf(0.f);
         }
-    } else {  // 2: weight [C][1][9] -> [9][C];   3: weight [1][C][9] -> [9][C]
+    } else if (part_ix == 0) {  // 2: weight [C][1][9] -> [9][C];   3: weight [1][C][9] -> [9][C]   (tiny: one of the split blocks)
         float* dst = (float*)(pack + L[F_PACK]);
         for (long e = threadIdx.x; e < (long)rows * in; e += 256) {
             const int o = row0 + (int)(e / in), i = (int)(e % in);
@@ -229,7 +237,7 @@ extern "C" int ieagan_sn_forward(const long* tab, const int* blocks, int nblocks
     hipLaunchKernelGGL(sn_phase1_kernel, dim3(nblocks), dim3(256), 0, st, tab, blocks, (const float*)params, part);
     hipLaunchKernelGGL(sn_phase1b_kernel, dim3(ncblocks), dim3(256), 0, st, tab, cblocks, (const float*)part, ctx);
     hipLaunchKernelGGL(sn_phase2_kernel, dim3(nblocks), dim3(256), 0, st, tab, blocks, (const float*)params, ctx, part, eps);
-    hipLaunchKernelGGL(sn_phase3_kernel, dim3(nblocks), dim3(256), 0, st, tab, blocks, params, ctx, (const float*)part, (char*)pack, eps, training);
+    hipLaunchKernelGGL(sn_phase3_kernel, dim3(nblocks * SN_P3SPLIT), dim3(256), 0, st, tab, blocks, params, ctx, (const float*)part, (char*)pack, eps, training);
     CHECK_LAUNCH("sn_forward");
     return 0;
 }
