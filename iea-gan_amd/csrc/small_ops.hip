@@ -194,13 +194,182 @@ __global__ __launch_bounds__(256) void rrm_attn_bwd_kernel(const float* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same two kernels for hd % 4 == 0 (every head of the path: 64 / 128): LDS rows padded to hd + 4 floats, so a row is 16-byte aligned and
+// 16 consecutive rows start on 16 different 4-bank groups -- every inner-product step is two ds_read_b128 per four FMAs instead of eight
+// ds_read_b32; the row softmax runs one wave per row (lanes = columns).  The scalar kernels above spent their time in LDS reads: 26.6 us a
+// launch for 40 tokens (forward), five launches per step on the critical path.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
+// inner product of two [hd] LDS rows: eight 16-byte reads requested per step, four independent partial sums (one running sum made every
+// step wait for its own LDS read: ~130 cycles x hd / 4 steps x 7 outputs per thread)
+__device__ __forceinline__ float row_dot(const float* a, const float* b, int hd4) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int d4 = 0;
+    for (; d4 + 4 <= hd4; d4 += 4) {
+        const f32x4 a0 = *(const f32x4*)(a + 4 * d4), a1 = *(const f32x4*)(a + 4 * d4 + 4), a2 = *(const f32x4*)(a + 4 * d4 + 8),
+                    a3 = *(const f32x4*)(a + 4 * d4 + 12);
+        const f32x4 b0 = *(const f32x4*)(b + 4 * d4), b1 = *(const f32x4*)(b + 4 * d4 + 4), b2 = *(const f32x4*)(b + 4 * d4 + 8),
+                    b3 = *(const f32x4*)(b + 4 * d4 + 12);
+        s0 += dot4(a0, b0);
+        s1 += dot4(a1, b1);
+        s2 += dot4(a2, b2);
+        s3 += dot4(a3, b3);
+    }
+    for (; d4 < hd4; ++d4) s0 += dot4(*(const f32x4*)(a + 4 * d4), *(const f32x4*)(b + 4 * d4));
+    return (s0 + s1) + (s2 + s3);
+}
+
+// rows of [S][hd] operands of this head -> LDS (NOPS operands, 16-byte loads, all of a batch in flight)
+template <int NOPS>
+__device__ __forceinline__ void rrm_stage(const float* const (&src)[NOPS], const long (&rstride)[NOPS], float* const (&dst)[NOPS], int S, int hd, int LD) {
+    const int hd4 = hd >> 2, tot = S * hd4;
+    for (int b0 = 0; b0 < tot; b0 += 4 * 256) {
+        f32x4 r[4][NOPS];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = min(b0 + u * 256 + (int)threadIdx.x, tot - 1);
+            const int s = idx / hd4, d4 = idx - s * hd4;
+#pragma unroll
+            for (int o = 0; o < NOPS; ++o) r[u][o] = *(const f32x4*)(src[o] + (long)s * rstride[o] + d4 * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = b0 + u * 256 + (int)threadIdx.x;
+            if (idx >= tot) continue;
+            const int s = idx / hd4, d4 = idx - s * hd4;
+#pragma unroll
+            for (int o = 0; o < NOPS; ++o) *(f32x4*)(dst[o] + s * LD + d4 * 4) = r[u][o];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void rrm_attn_fwd4_kernel(const float* __restrict__ qkv, float* __restrict__ out, float* __restrict__ att_out,
+                                                            int S, int Hh, int hd) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int LD = hd + 4, hd4 = hd >> 2;
+    float* q = sm;
+    float* k = q + S * LD;
+    float* v = k + S * LD;
+    float* att = v + S * LD;                       // [S][S]
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int E3 = Hh * 3 * hd, E = Hh * hd;
+    const float* base = qkv + (long)b * S * E3 + h * 3 * hd;
+    {
+        const float* const src[3] = {base, base + hd, base + 2 * hd};
+        const long rs[3] = {E3, E3, E3};
+        float* const dst[3] = {q, k, v};
+        rrm_stage<3>(src, rs, dst, S, hd, LD);
+    }
+    __syncthreads();
+    const float scale = rsqrtf((float)hd);
+    for (int idx = threadIdx.x; idx < S * S; idx += 256) {
+        const int i = idx / S, j = idx - i * S;
+        att[idx] = row_dot(q + i * LD, k + j * LD, hd4) * scale;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* ao = att_out + ((long)b * Hh + h) * S * S;
+    for (int i = wave; i < S; i += 4) {            // row softmax: one wave per row, lane = column (S <= 64)
+        const float x = lane < S ? att[i * S + lane] : -1e30f;
+        const float m = wave_max(x);
+        const float e = lane < S ? __expf(x - m) : 0.f;
+        const float p = e / wave_sum(e);
+        if (lane < S) {
+            att[i * S + lane] = p;
+            ao[i * S + lane] = p;
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < S * hd4; idx += 256) {
+        const int i = idx / hd4, d4 = idx - i * hd4;
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+        int j = 0;
+        for (; j + 4 <= S; j += 4) {                // four rows requested per step, two partial sums
+            const f32x4 v0 = *(const f32x4*)(v + j * LD + 4 * d4), v1 = *(const f32x4*)(v + (j + 1) * LD + 4 * d4),
+                        v2 = *(const f32x4*)(v + (j + 2) * LD + 4 * d4), v3 = *(const f32x4*)(v + (j + 3) * LD + 4 * d4);
+            const float p0 = att[i * S + j], p1 = att[i * S + j + 1], p2 = att[i * S + j + 2], p3 = att[i * S + j + 3];
+            a0 += p0 * v0 + p2 * v2;
+            a1 += p1 * v1 + p3 * v3;
+        }
+        for (; j < S; ++j) a0 += att[i * S + j] * *(const f32x4*)(v + j * LD + 4 * d4);
+        *(f32x4*)(out + ((long)b * S + i) * E + h * hd + 4 * d4) = a0 + a1;
+    }
+}
+
+__global__ __launch_bounds__(256) void rrm_attn_bwd4_kernel(const float* __restrict__ qkv, const float* __restrict__ att_in,
+                                                            const float* __restrict__ dout, float* __restrict__ dqkv, int S, int Hh, int hd) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int LD = hd + 4, hd4 = hd >> 2;
+    float* q = sm;
+    float* k = q + S * LD;
+    float* v = k + S * LD;
+    float* go = v + S * LD;                        // dout of this head [S][hd]
+    float* att = go + S * LD;                      // [S][S]
+    float* ds = att + S * S;                       // d score [S][S]
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int E3 = Hh * 3 * hd, E = Hh * hd;
+    const float* base = qkv + (long)b * S * E3 + h * 3 * hd;
+    {
+        const float* const src[4] = {base, base + hd, base + 2 * hd, dout + (long)b * S * E + h * hd};
+        const long rs[4] = {E3, E3, E3, E};
+        float* const dst[4] = {q, k, v, go};
+        rrm_stage<4>(src, rs, dst, S, hd, LD);
+    }
+    const float* ai = att_in + ((long)b * Hh + h) * S * S;
+    {
+        const int tot = S * S;
+        float ra[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) ra[u] = ai[min(u * 256 + (int)threadIdx.x, tot - 1)];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (u * 256 + (int)threadIdx.x < tot) att[u * 256 + threadIdx.x] = ra[u];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < S * S; idx += 256) {    // d att_ij = dout_i . v_j
+        const int i = idx / S, j = idx - i * S;
+        ds[idx] = row_dot(go + i * LD, v + j * LD, hd4);
+    }
+    __syncthreads();
+    const float scale = rsqrtf((float)hd);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = wave; i < S; i += 4) {                       // softmax backward per row (one wave per row), folded with 1/sqrt(hd)
+        const float a = lane < S ? att[i * S + lane] : 0.f, d = lane < S ? ds[i * S + lane] : 0.f;
+        const float dot = wave_sum(a * d);
+        if (lane < S) ds[i * S + lane] = a * (d - dot) * scale;
+    }
+    __syncthreads();
+    float* ob = dqkv + (long)b * S * E3 + h * 3 * hd;
+    for (int idx = threadIdx.x; idx < S * hd4; idx += 256) {
+        const int i = idx / hd4, d4 = idx - i * hd4;
+        f32x4 dq = {0.f, 0.f, 0.f, 0.f}, dk = dq, dv = dq;
+#pragma unroll 4
+        for (int j = 0; j < S; ++j) {               // (three independent sums per step; unrolled: four steps of reads in flight)
+            dq += ds[i * S + j] * *(const f32x4*)(k + j * LD + 4 * d4);
+            dk += ds[j * S + i] * *(const f32x4*)(q + j * LD + 4 * d4);
+            dv += att[j * S + i] * *(const f32x4*)(go + j * LD + 4 * d4);
+        }
+        *(f32x4*)(ob + (long)i * E3 + 4 * d4) = dq;
+        *(f32x4*)(ob + (long)i * E3 + hd + 4 * d4) = dk;
+        *(f32x4*)(ob + (long)i * E3 + 2 * hd + 4 * d4) = dv;
+    }
+}
+
 extern "C" int ieagan_rrm_attention_fwd(const float* qkv, float* out, float* att, int B, int S, int H, int hd, void* stream) {
     CHECK_ARG(S >= 1 && S <= SMAX && hd >= 1, "rrm_attention: S must be <= %d", SMAX);
-    const size_t lds = (size_t)(3 * S * (hd + 1) + S * S) * 4;
+    const bool v4 = (hd & 3) == 0;
+    const size_t lds = (size_t)(3 * S * (hd + (v4 ? 4 : 1)) + S * S) * 4;
     CHECK_ARG(lds <= 150 * 1024, "rrm_attention: head does not fit LDS");
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof("rrm_attention_fwd", 4.0 * B * H * S * S * hd, 0.0, st);
-    hipLaunchKernelGGL(rrm_attn_fwd_kernel, dim3(H, B), dim3(256), lds, st, qkv, out, att, S, H, hd);
+    if (v4) hipLaunchKernelGGL(rrm_attn_fwd4_kernel, dim3(H, B), dim3(256), lds, st, qkv, out, att, S, H, hd);
+    else hipLaunchKernelGGL(rrm_attn_fwd_kernel, dim3(H, B), dim3(256), lds, st, qkv, out, att, S, H, hd);
     CHECK_LAUNCH("rrm_attention_fwd");
     return 0;
 }
@@ -208,11 +377,13 @@ extern "C" int ieagan_rrm_attention_fwd(const float* qkv, float* out, float* att
 extern "C" int ieagan_rrm_attention_bwd(const float* qkv, const float* att, const float* dout, float* dqkv, int B, int S, int H, int hd,
                                         void* stream) {
     CHECK_ARG(S >= 1 && S <= SMAX && hd >= 1, "rrm_attention: S must be <= %d", SMAX);
-    const size_t lds = (size_t)(4 * S * (hd + 1) + 2 * S * S) * 4;
+    const bool v4 = (hd & 3) == 0;
+    const size_t lds = (size_t)(4 * S * (hd + (v4 ? 4 : 1)) + 2 * S * S) * 4;
     CHECK_ARG(lds <= 150 * 1024, "rrm_attention: head does not fit LDS");
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof("rrm_attention_bwd", 8.0 * B * H * S * S * hd, 0.0, st);
-    hipLaunchKernelGGL(rrm_attn_bwd_kernel, dim3(H, B), dim3(256), lds, st, qkv, att, dout, dqkv, S, H, hd);
+    if (v4) hipLaunchKernelGGL(rrm_attn_bwd4_kernel, dim3(H, B), dim3(256), lds, st, qkv, att, dout, dqkv, S, H, hd);
+    else hipLaunchKernelGGL(rrm_attn_bwd_kernel, dim3(H, B), dim3(256), lds, st, qkv, att, dout, dqkv, S, H, hd);
     CHECK_LAUNCH("rrm_attention_bwd");
     return 0;
 }
