@@ -416,3 +416,40 @@ def test_launched_kernels_are_spill_free_except_the_listed_ones():
                 bad.append((short, worst))
     assert matched >= 100, matched
     assert not bad, bad
+
+
+def test_weight_gradient_pixel_splits_follow_the_traffic_rule():
+    """The launch plan of ieagan_conv_wgrad (pure host code: runs without a GPU) at the production shapes: the partial dW slabs a launch writes
+    and reads back never weigh more than twice its operands -- unless that would make a block walk more than 16 tiles -- and small dW x few
+    splits stays with direct accumulation (no workspace).  DESIGN section 3, conv_wgrad (b)."""
+    import _hip
+    if not os.path.exists(_hip.LIB_PATH):
+        pytest.skip("library not built")
+    lib = ctypes.CDLL(_hip.LIB_PATH)
+    lib.ieagan_conv_wgrad_workspace.restype = ctypes.c_long
+    lib.ieagan_conv_wgrad_workspace.argtypes = [ctypes.POINTER(_hip.WgradDesc), ctypes.c_int]
+    N = 40
+    shapes = [(64, 64, 32, 96, 9, 0), (256, 64, 32, 96, 1, 0), (64, 64, 64, 192, 9, 0), (128, 128, 8, 24, 9, 0), (128, 128, 16, 48, 9, 0),
+              (128, 32, 64, 192, 1, 0), (512, 128, 8, 24, 1, 0), (32, 128, 64, 192, 1, 2), (128, 512, 4, 12, 1, 0), (16, 16, 256, 768, 9, 0)]
+    seen_direct = seen_slabs = 0
+    for cin, cout, h, w, taps, rs in shapes:
+        hs, ws = (2 * h, 2 * w) if rs == 2 else (h, w)
+        kpad = ((taps * cin + 31) // 32) * 32
+        src = _hip.SrcDesc(16, cin, hs, ws, rs, None, None, 0, 1)
+        d = _hip.WgradDesc(N, h, w, cin, cout, taps, kpad, src, 16, cout, 16, 0, 0, None, None)
+        elems = lib.ieagan_conv_wgrad_workspace(ctypes.byref(d), 1)
+        d.partials = 16                                   # "a workspace exists": the plan of the two-stage form
+        elems2 = lib.ieagan_conv_wgrad_workspace(ctypes.byref(d), 1)
+        assert elems2 > 0 and elems2 % (cout * kpad) == 0, (cin, cout, h, w, elems2)
+        splits = elems2 // (cout * kpad)
+        tiles = N * ((h + 7) // 8) * ((w + 15) // 16)
+        in_bytes = 2.0 * N * (hs * ws * cin + h * w * cout)
+        slab_rw = 2.0 * splits * 4.0 * cout * kpad
+        assert slab_rw <= 2.0 * in_bytes * 1.02 or splits <= max(2, -(-tiles // 16)), (cin, cout, h, w, splits, slab_rw / in_bytes)
+        assert -(-tiles // splits) <= 64, (cin, cout, h, w, splits, tiles)            # no block walks the whole map either
+        if elems == 0:
+            seen_direct += 1
+            assert splits * 4 * cout * taps * cin < 8 << 20, (cin, cout, h, w)          # direct accumulation only below 8 MB of adds
+        else:
+            seen_slabs += 1
+    assert seen_direct >= 2 and seen_slabs >= 4, (seen_direct, seen_slabs)
