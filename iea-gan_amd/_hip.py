@@ -60,6 +60,10 @@ class Conv3x3BwdDesc(C.Structure):
                 ("colsum", vp), ("flags", C.c_int), ("bn_slots", C.c_int)]
 
 
+class ReduceItem(C.Structure):
+    _fields_ = [("partials", vp), ("dw", vp), ("S", C.c_int), ("Cout", C.c_int), ("Kpad", C.c_int), ("K", C.c_int)]
+
+
 class DStemDesc(C.Structure):
     _fields_ = [("img", vp), ("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("w_in", vp), ("b_in", vp), ("w1", vp), ("b1", vp), ("wsc", vp),
                 ("bsc", vp), ("h1", vp), ("p0", vp), ("sc", vp), ("dh1", vp), ("dp0", vp), ("w1_bwd", vp), ("dw_in", vp), ("db_in", vp),
@@ -71,7 +75,7 @@ class ProfRec(C.Structure):
                 ("flops", C.c_double), ("bytes", C.c_double), ("bytes_min", C.c_double)]
 
 
-ABI_VERSION = 10           # include/ieagan_hip.h: IEAGAN_ABI_VERSION
+ABI_VERSION = 11           # include/ieagan_hip.h: IEAGAN_ABI_VERSION
 i, f, l = C.c_int, C.c_float, C.c_long
 _SIGS = {
     "ieagan_abi_version": [],
@@ -90,6 +94,7 @@ _SIGS = {
     "ieagan_conv3x3_bwd_slots": [C.POINTER(Conv3x3BwdDesc)],
     "ieagan_conv1x1_bwd_slots": [C.POINTER(Conv1x1BwdDesc)],
     "ieagan_wgrad_reduce": [vp, vp, i, i, i, i, vp],
+    "ieagan_wgrad_reduce_batched": [C.POINTER(ReduceItem), i, vp],
     "ieagan_conv_stats_slots": [C.POINTER(ConvDesc)],
     "ieagan_d_stem_fwd": [C.POINTER(DStemDesc), vp],
     "ieagan_d_stem_bwd": [C.POINTER(DStemDesc), vp],

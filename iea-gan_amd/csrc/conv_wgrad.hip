@@ -388,12 +388,13 @@ static void launch_wgrad_pro(const WgradArgs& a, hipStream_t st, int mt, dim3 gr
 // 4..36 live threads per block for the 1x1 / C = 16 layers, each walking 32 slabs serially); the four lanes meet in LDS, slab
 // chunks (blockIdx.y, at most 32 so that no address sees more than 32 atomics) in float atomics.
 #define WG_TWO_STAGE_MIN_BYTES (8L << 20)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, int chunk, int n4, int kp4, int K) {
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part, float* __restrict__ dw, int S, int chunk, int n4, int kp4, int K,
+                                                  int bx, int by, int ny) {
     __shared__ f32x4 red[3][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + tx;
+    const int i = bx * 64 + tx;
     const bool live = i < n4 && (i % kp4) * 4 < K;            // Kpad padding columns are not written by the first stage
-    const int s0 = blockIdx.y * chunk, s1 = min(s0 + chunk, S);
+    const int s0 = by * chunk, s1 = min(s0 + chunk, S);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (live) {
         const f32x4* p = (const f32x4*)part + i;
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (ty > 0 || !live) return;
     acc += red[0][tx] + red[1][tx] + red[2][tx];
     float* d = dw + (long)i * 4;
-    if (gridDim.y == 1) {
+    if (ny == 1) {
         f32x4 v = *(f32x4*)d;
         *(f32x4*)d = v + acc;
     } else {
@@ -414,18 +415,76 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int S, int chunk, int n4, int kp4, int K) {
+    wgrad_reduce_body(part, dw, S, chunk, n4, kp4, K, blockIdx.x, blockIdx.y, gridDim.y);
+}
+
+// slab-chunk split of one fold: ~2 blocks per CU, at least 16 slabs per block, at most 32 adders per address
+static void wgrad_reduce_geometry(int S, int Cout, int Kpad, int& bx, int& zc, int& chunk) {
+    const int n4 = Cout * (Kpad / 4);
+    bx = (n4 + 63) / 64;
+    zc = (512 + bx - 1) / bx;
+    if (zc > 32) zc = 32;
+    if (zc > (S + 15) / 16) zc = (S + 15) / 16;
+    if (zc < 1) zc = 1;
+    chunk = (S + zc - 1) / zc;
+    zc = (S + chunk - 1) / chunk;
+}
+
 // second stage, also for other producers of partial slabs (conv1x1_bwd.hip)
 int wgrad_reduce_launch(const float* part, float* dw, int S, int Cout, int Kpad, int K, hipStream_t st) {
-    const int n4 = Cout * (Kpad / 4);
-    const int bx = (n4 + 63) / 64;
-    int zc = (512 + bx - 1) / bx;                   // ~2 blocks per CU
-    if (zc > 32) zc = 32;
-    if (zc > (S + 15) / 16) zc = (S + 15) / 16;     // at least 16 slabs per block (4 per lane)
-    if (zc < 1) zc = 1;
-    const int chunk = (S + zc - 1) / zc;
-    zc = (S + chunk - 1) / chunk;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(bx, zc), dim3(256), 0, st, part, dw, S, chunk, n4, Kpad / 4, K);
+    int bx, zc, chunk;
+    wgrad_reduce_geometry(S, Cout, Kpad, bx, zc, chunk);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(bx, zc), dim3(256), 0, st, part, dw, S, chunk, Cout * (Kpad / 4), Kpad / 4, K);
     CHECK_LAUNCH("wgrad_reduce");
+    return 0;
+}
+
+// Several folds in ONE launch (ieagan_wgrad_reduce_batched): the whole-backward kernels of a pass leave their slabs (IEAGAN_BWD_NO_REDUCE) and
+// the pass folds them all at its end, right before the spectral-norm backward that first reads dW -- instead of one ~8 us launch (and a
+// drained chip) behind each of the 36 kernels.  The item table travels by value in the kernel argument.
+#define WGR_MAX_ITEMS 32
+struct WgrBatch {
+    const float* part[WGR_MAX_ITEMS];
+    float* dw[WGR_MAX_ITEMS];
+    int S[WGR_MAX_ITEMS], chunk[WGR_MAX_ITEMS], n4[WGR_MAX_ITEMS], kp4[WGR_MAX_ITEMS], K[WGR_MAX_ITEMS], bx[WGR_MAX_ITEMS], zc[WGR_MAX_ITEMS];
+    int blk0[WGR_MAX_ITEMS + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(WgrBatch b) {
+    int it = 0;
+    while (it + 1 < b.n && (int)blockIdx.x >= b.blk0[it + 1]) ++it;          // block-uniform
+    const int local = blockIdx.x - b.blk0[it];
+    wgrad_reduce_body(b.part[it], b.dw[it], b.S[it], b.chunk[it], b.n4[it], b.kp4[it], b.K[it], local % b.bx[it], local / b.bx[it], b.zc[it]);
+}
+
+extern "C" int ieagan_wgrad_reduce_batched(const ieagan_reduce_item* items, int n, void* stream) {
+    CHECK_ARG(items != nullptr && n >= 1, "wgrad_reduce_batched: empty item list");
+    hipStream_t st = (hipStream_t)stream;
+    double bytes = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const ieagan_reduce_item& q = items[i];
+        CHECK_ARG(q.partials != nullptr && q.dw != nullptr && q.S >= 1 && q.Cout >= 1 && q.Kpad % 4 == 0 && q.K <= q.Kpad, "wgrad_reduce_batched: bad item %d", i);
+        bytes += 4.0 * ((double)q.S + 2.0) * q.Cout * q.Kpad;
+    }
+    ProfScope prof("wgrad_reduce", 0.0, bytes, st);
+    for (int i0 = 0; i0 < n; i0 += WGR_MAX_ITEMS) {
+        WgrBatch b;
+        b.n = n - i0 < WGR_MAX_ITEMS ? n - i0 : WGR_MAX_ITEMS;
+        int blocks = 0;
+        for (int i = 0; i < b.n; ++i) {
+            const ieagan_reduce_item& q = items[i0 + i];
+            int bx, zc, chunk;
+            wgrad_reduce_geometry(q.S, q.Cout, q.Kpad, bx, zc, chunk);
+            b.part[i] = q.partials; b.dw[i] = q.dw; b.S[i] = q.S; b.chunk[i] = chunk; b.n4[i] = q.Cout * (q.Kpad / 4); b.kp4[i] = q.Kpad / 4;
+            b.K[i] = q.K; b.bx[i] = bx; b.zc[i] = zc; b.blk0[i] = blocks;
+            blocks += bx * zc;
+        }
+        b.blk0[b.n] = blocks;
+        hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3(blocks), dim3(256), 0, st, b);
+    }
+    CHECK_LAUNCH("wgrad_reduce_batched");
     return 0;
 }
 

@@ -116,10 +116,12 @@ class ExecOptions:
     b1_flags            ieagan_conv1x1_bwd_desc.flags (benchmarks: H.B1_OCC2 / H.B1_OCC3)
     fused_reduce_side_stream   the slab folds of the whole-backward kernels on the weight-gradient side stream (with wgrad_side_stream).
                         OFF: measured 36.75-37.0 vs 34.75-34.97 ms per step on one box -- the side stream then sits behind every fused kernel
-                        of the large maps and the weight gradients queued after it start late"""
+                        of the large maps and the weight gradients queued after it start late
+    fused_reduce_batched       the slab folds of the whole-backward kernels of a pass in ONE launch at the end of the pass (``SNPass.flush``:
+                        nothing reads dW earlier) instead of one launch behind each of them"""
     FIELDS = dict(wgrad_side_stream=True, two_stage_wgrad=True, use_tr_read=True, fuse_bn_backward=True, fuse_shortcut_grad=True,
                   fuse_1x1_backward=True, fuse_1x1_min_pixels=1 << 16, fuse_3x3_backward=True, fuse_3x3_min_pixels=1 << 16,
-                  fuse_d_stem=True, b1_flags=0, fused_reduce_side_stream=False)
+                  fuse_d_stem=True, b1_flags=0, fused_reduce_side_stream=False, fused_reduce_batched=True)
     __slots__ = tuple(FIELDS)
 
     def __init__(self, like=None, **kw):
@@ -179,6 +181,7 @@ class SNPass:
     def __init__(self, bank, ctx):
         self.bank, self.ctx, self.arena, self._ok = bank, ctx, None, None
         self.side = None             # side stream carrying this pass's weight-gradient launches (joined in flush)
+        self.reduces = []            # (slab workspace, dW view, S, Cout, Kpad, K) of the whole-backward kernels: folded in ONE launch by flush
         self.stream = torch.cuda.current_stream(ctx.device)      # the stream this pass runs on (autograd runs its backward there too)
 
     def usable(self) -> bool:
@@ -214,6 +217,14 @@ class SNPass:
         if self.side is not None:
             cur.wait_stream(self.side)
             self.side = None
+        if self.reduces:                # the slab sets the whole-backward kernels of this pass left behind (fused_reduce_batched)
+            items = (H.ReduceItem * len(self.reduces))(*[H.ReduceItem(ws.data_ptr(), dwp.data_ptr(), S, Cout, kpad, K)
+                                                        for ws, dwp, S, Cout, kpad, K in self.reduces])
+            H.call("ieagan_wgrad_reduce_batched", items, len(self.reduces), H.stream())
+            if cur != self.stream:
+                for ws, *_ in self.reduces:
+                    ws.record_stream(cur)
+            self.reduces = []
         b = self.bank
         H.call("ieagan_sn_backward_batched", b.bwd["table"].data_ptr(), b.bwd["work"].data_ptr(), b.bwd["nwork"], b.arena.data_ptr(),
                self.ctx.data_ptr(), self.arena.data_ptr(), b.owner.grad.data_ptr(), H.stream())
@@ -712,9 +723,15 @@ def _fused_bwd_launch(name, d, rec, ws, dwp, Cout, K, operands):
     nothing reads dW before the end of the pass (``SNPass.flush`` joins the side stream)."""
     o = opts_of(rec)
     side_ok = ws is not None and o.wgrad_side_stream and o.fused_reduce_side_stream and getattr(rec, "deferred", False)
-    if side_ok:
+    pass_ = getattr(rec, "pass_", None)
+    batch_ok = (not side_ok and ws is not None and o.fused_reduce_batched and getattr(rec, "deferred", False) and pass_ is not None
+                and pass_.arena is not None)
+    if side_ok or batch_ok:
         d.flags |= H.BWD_NO_REDUCE
     H.call(name, d, H.stream())
+    if batch_ok:                        # folded with the other slab sets of the pass in SNPass.flush
+        pass_.reduces.append((ws, dwp, ws.numel() // (Cout * rec.kpad), Cout, rec.kpad, K))
+        return
     if side_ok:
         dev = ws.device
         fork = torch.cuda.Event()

@@ -19,7 +19,7 @@ extern "C" {
 #endif
 
 const char* ieagan_last_error(void);
-#define IEAGAN_ABI_VERSION 10       /* bumped whenever a struct layout or a signature in this header changes */
+#define IEAGAN_ABI_VERSION 11       /* bumped whenever a struct layout or a signature in this header changes */
 int ieagan_abi_version(void);        /* == IEAGAN_ABI_VERSION of the header the library was built from */
 
 /* ---- profiling hooks (bench.py): per-kernel HIP-event timing on the launch stream ---- */
@@ -162,6 +162,14 @@ int ieagan_conv1x1_bwd_slots(const ieagan_conv1x1_bwd_desc* d);      /* blocks p
 /* second stage of every two-stage weight-gradient accumulation: dw[Cout][Kpad] += sum over the S slabs of `partials` ([S][Cout][Kpad]; columns
  * k >= K are padding).  S = workspace floats / (Cout * Kpad). */
 int ieagan_wgrad_reduce(const float* partials, float* dw, int S, int Cout, int Kpad, int K, void* stream);
+/* the same for n slab sets in one launch: the whole-backward kernels of a backward pass leave their slabs (IEAGAN_BWD_NO_REDUCE), the pass
+ * folds them together at its end (nothing reads dW earlier) */
+typedef struct {
+    const float* partials;    /* [S][Cout][Kpad] */
+    float* dw;                /* [Cout][Kpad], accumulated */
+    int S, Cout, Kpad, K;
+} ieagan_reduce_item;
+int ieagan_wgrad_reduce_batched(const ieagan_reduce_item* items, int n, void* stream);
 
 /* ---- the whole backward of a 3x3 convolution with Cin = Cout = C in {16, 32} on a large feature map in one launch (conv3x3_bwd.hip) ----
  * Replaces, per layer and backward pass, ieagan_effgrad -> ieagan_conv_forward (as dgrad) [-> ieagan_prologue_bwd] -> ieagan_conv_wgrad, i.e.
